@@ -1,0 +1,152 @@
+/*
+ * tekken_hip.h -- C ABI of the MI355X-native batch tokenization path for tekken-rs.
+ *
+ * The reference has no FFI seam today; this boundary is inserted at its single call into
+ * the third-party BPE engine:
+ *
+ *     let (tokens, _) = self.tekkenizer.encode(text, &HashSet::new());   src/tekkenizer.rs:384-386
+ *     CoreBPE::new(mergeable_ranks.clone(), special_tokens, pattern)      src/tekkenizer.rs:125
+ *
+ * plus the id shift and BOS/EOS insertion of src/tekkenizer.rs:390-402, which are fused
+ * into the device emit.  Everything is plain pointers and sizes; no C++ or torch types.
+ * The Rust binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: a context serialises its calls internally (one HIP stream + mutex), so it can
+ * back the reference's `&self` / `Sync` Tekkenizer (tests/test_tokenizer_output.rs:5-12).
+ */
+#ifndef TEKKEN_HIP_H
+#define TEKKEN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes; the Rust shim maps them onto TokenizerError (src/errors.rs:23-59) ---- */
+#define TK_OK 0
+#define TK_ERR_INVALID_CONFIG (-1)   /* -> TokenizerError::InvalidConfig   (errors.rs:45-46) */
+#define TK_ERR_RUNTIME (-2)          /* -> TokenizerError::Tokenizers(msg) (errors.rs:37-38) */
+#define TK_ERR_INVALID_UTF8 (-3)     /* -> TokenizerError::Tokenizers(msg); &str can never trigger it */
+#define TK_ERR_NO_DEVICE (-4)        /* -> TokenizerError::Tokenizers(msg): no gfx950 device / HIP missing */
+#define TK_ERR_INVALID_ARG (-5)      /* -> TokenizerError::InvalidConfig */
+#define TK_ERR_IO (-6)               /* -> TokenizerError::Io              (errors.rs:25-26) */
+#define TK_ERR_JSON (-7)             /* -> TokenizerError::Json            (errors.rs:29-30) */
+#define TK_ERR_BASE64 (-8)           /* -> TokenizerError::Base64          (errors.rs:33-34) */
+#define TK_ERR_TOKEN_NOT_FOUND (-9)  /* -> TokenizerError::TokenNotFound   (errors.rs:49-50) */
+#define TK_ERR_SPECIAL_POLICY (-10)  /* -> TokenizerError::SpecialTokenPolicy (errors.rs:53-54) */
+
+typedef struct tk_ctx tk_ctx;
+
+/* ------------------------------------------------------------------------------------------
+ * Engine level: replaces CoreBPE::new / CoreBPE::encode.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces `CoreBPE::new(mergeable_ranks, {}, pattern)` (src/tekkenizer.rs:122-126).
+ * token_bytes/token_offsets: rank i has bytes token_bytes[token_offsets[i] .. token_offsets[i+1]);
+ * the table must already satisfy the checks of reload_mergeable_ranks (src/tekkenizer.rs:776-816)
+ * -- the checks are repeated and TK_ERR_INVALID_CONFIG is returned if they fail.
+ * bos_id/eos_id are the FINAL ids of "<s>" / "</s>" (src/tekkenizer.rs:286-297).
+ * The split pattern is the literal of src/tekkenizer.rs:123 (the JSON `pattern` is ignored by the
+ * reference, :74).  Inputs are copied.  device_id: HIP device ordinal. */
+int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_offsets, uint32_t n_ranks,
+                  uint32_t num_special_tokens, uint32_t bos_id, uint32_t eos_id, int device_id,
+                  tk_ctx** out_ctx);
+
+/* Frees device and host state.  NULL is a no-op. */
+void tk_ctx_destroy(tk_ctx* ctx);
+
+/* Message of the last failing call on this context (or of the last failing tk_ctx_create /
+ * tk_tokenizer_* constructor on this thread when ctx == NULL).  Never NULL. */
+const char* tk_last_error(const tk_ctx* ctx);
+
+typedef struct tk_result {
+    uint32_t* ids;      /* n_ids final token ids (shifted, BOS/EOS in place), document order */
+    uint64_t* offsets;  /* n_docs + 1 entries: document d owns ids[offsets[d] .. offsets[d+1]) */
+    uint64_t n_ids;
+    uint64_t n_docs;
+} tk_result;
+
+/* Batch form of `Tekkenizer::encode(text, add_bos, add_eos)` (src/tekkenizer.rs:378-405):
+ * document d = bytes[doc_offsets[d] .. doc_offsets[d+1]), for every d exactly what the reference
+ * returns for that &str.  Host buffers in, host buffers out (pinned, owned by the library until
+ * tk_free_result).  Each document must be valid UTF-8 (a Rust &str always is); pass
+ * validate_utf8 != 0 to have that checked (TK_ERR_INVALID_UTF8). */
+int tk_encode_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                    int add_bos, int add_eos, int validate_utf8, tk_result* out);
+void tk_free_result(tk_result* r);
+
+/* Same computation with inputs already resident in HBM (hipMalloc'ed on the context's device):
+ * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64.  Work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the
+ * stream has drained.  *d_ids / *d_out_offsets are device buffers owned by the context, valid
+ * until the next call on it; *n_ids = total ids. */
+int tk_encode_batch_device(tk_ctx* ctx, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
+                           uint64_t n_bytes, int add_bos, int add_eos, void* hip_stream, void** d_ids,
+                           void** d_out_offsets, uint64_t* n_ids);
+
+/* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
+ * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
+int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);
+
+/* Counters of the last call: documents handled by the long-piece path, windows processed. */
+int tk_last_stats(const tk_ctx* ctx, uint64_t* n_long_docs, uint64_t* reserved);
+
+/* Pre-tokenization split only (vocab-free): out_is_start[i] = 1 iff a piece starts at byte i of
+ * the packed buffer (host in / host out).  Debug / parity entry for the split rules. */
+int tk_split_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                   uint8_t* out_is_start);
+
+/* ------------------------------------------------------------------------------------------
+ * Tokenizer level: the host-side mirror of tekken::tekkenizer::Tekkenizer, exported so that
+ * non-C++ hosts (the Rust shim, Python tests) can drive loader + encode + decode.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tk_tokenizer tk_tokenizer;
+
+#define TK_POLICY_IGNORE 0  /* SpecialTokenPolicy::Ignore  (src/special_tokens.rs:128-136) */
+#define TK_POLICY_KEEP 1    /* SpecialTokenPolicy::Keep  */
+#define TK_POLICY_RAISE 2   /* SpecialTokenPolicy::Raise */
+
+/* Tekkenizer::from_file (src/tekkenizer.rs:222-248).  device_id < 0 => host-only object
+ * (loader, decode and accessors work; encode returns TK_ERR_NO_DEVICE). */
+int tk_tokenizer_from_file(const char* path, int device_id, tk_tokenizer** out);
+/* Same, from an in-memory tekken.json document. */
+int tk_tokenizer_from_json(const char* json, size_t json_len, int device_id, tk_tokenizer** out);
+void tk_tokenizer_destroy(tk_tokenizer* t);
+/* Error text of the last failing call on t (t == NULL: last failing constructor on this thread). */
+const char* tk_tokenizer_last_error(const tk_tokenizer* t);
+
+/* Tekkenizer::encode (src/tekkenizer.rs:378-405) for one document; *ids is malloc'ed, free with
+ * tk_free_ids. */
+int tk_tokenizer_encode(tk_tokenizer* t, const char* text, size_t len, int add_bos, int add_eos,
+                        uint32_t** ids, size_t* n_ids);
+/* Batch addition (no reference equivalent; see tk_encode_batch). */
+int tk_tokenizer_encode_batch(tk_tokenizer* t, const uint8_t* bytes, const uint64_t* doc_offsets,
+                              uint64_t n_docs, int add_bos, int add_eos, tk_result* out);
+void tk_free_ids(uint32_t* ids);
+
+/* Tekkenizer::decode (src/tekkenizer.rs:436-443); *text is malloc'ed (not NUL terminated beyond
+ * *len, but a trailing NUL is added for convenience), free with tk_free_text. */
+int tk_tokenizer_decode(tk_tokenizer* t, const uint32_t* ids, size_t n_ids, int policy, char** text,
+                        size_t* len);
+void tk_free_text(char* text);
+
+/* Accessors (src/tekkenizer.rs:260-350, 574-600, 617-695). */
+uint32_t tk_tokenizer_vocab_size(const tk_tokenizer* t);
+uint32_t tk_tokenizer_num_special_tokens(const tk_tokenizer* t);
+const char* tk_tokenizer_version(const tk_tokenizer* t); /* "v3" | "v7" | "v11" | "v13" */
+int tk_tokenizer_control_token(tk_tokenizer* t, const char* name, uint32_t* id); /* get_control_token */
+int tk_tokenizer_is_special(const tk_tokenizer* t, uint32_t id);
+int tk_tokenizer_is_byte(const tk_tokenizer* t, uint32_t id);
+int tk_tokenizer_id_to_piece(tk_tokenizer* t, uint32_t id, char** text, size_t* len);
+int tk_tokenizer_id_to_byte_piece(tk_tokenizer* t, uint32_t id, int policy, uint8_t** bytes, size_t* len);
+/* The engine context behind the tokenizer (NULL for host-only objects). */
+tk_ctx* tk_tokenizer_ctx(tk_tokenizer* t);
+/* The validated rank table (for building an oracle beside it in tests). */
+int tk_tokenizer_rank_table(const tk_tokenizer* t, const uint8_t** blob, const uint32_t** offsets,
+                            uint32_t* n_ranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

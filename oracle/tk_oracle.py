@@ -1,0 +1,117 @@
+"""ctypes binding of the CPU oracle (oracle/tk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  Parity status: see tk_oracle.h
+("parity unpinned" at token-id level; split pinned against Python `regex`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libtk_oracle.so")
+    src = os.path.join(_HERE, "tk_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libtk_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.tk_oracle_new.restype = ctypes.c_void_p
+        L.tk_oracle_new.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        L.tk_oracle_free.argtypes = [ctypes.c_void_p]
+        L.tk_oracle_split.restype = ctypes.c_size_t
+        L.tk_oracle_split.argtypes = [u8p, ctypes.c_size_t, u32p, ctypes.c_size_t]
+        L.tk_oracle_encode.restype = ctypes.c_size_t
+        L.tk_oracle_encode.argtypes = [ctypes.c_void_p, u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u32p,
+                                       ctypes.c_size_t]
+        L.tk_oracle_encode_batch.restype = ctypes.c_uint64
+        L.tk_oracle_encode_batch.argtypes = [ctypes.c_void_p, u8p, u64p, ctypes.c_uint64, ctypes.c_int,
+                                             ctypes.c_int, u32p, u64p, ctypes.c_int]
+        L.tk_oracle_class.restype = ctypes.c_int
+        L.tk_oracle_class.argtypes = [ctypes.c_uint32]
+        L.tk_oracle_fnv1a.restype = ctypes.c_uint64
+        L.tk_oracle_fnv1a.argtypes = [u32p, ctypes.c_uint64]
+        _LIB = L
+    return _LIB
+
+
+def _p(arr, ct):
+    return arr.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def split(text: bytes):
+    """Piece start offsets of `text` under the hard-coded pattern (src/tekkenizer.rs:123)."""
+    n = len(text)
+    buf = np.frombuffer(text, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+    starts = np.zeros(max(n, 1), np.uint32)
+    k = lib().tk_oracle_split(_p(buf, ctypes.c_uint8), n, _p(starts, ctypes.c_uint32), n)
+    return starts[:k].tolist()
+
+
+def split_pieces(text: bytes):
+    s = split(text) + [len(text)]
+    return [text[s[i]:s[i + 1]] for i in range(len(s) - 1)]
+
+
+class Oracle:
+    """Rank table + encode, the CPU stand-in for CoreBPE + Tekkenizer::encode."""
+
+    def __init__(self, token_bytes, num_special, bos_id, eos_id):
+        self.tokens = list(token_bytes)
+        offs = np.zeros(len(self.tokens) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(t) for t in self.tokens], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(self.tokens) or b"\0", dtype=np.uint8)
+        self.num_special, self.bos_id, self.eos_id = num_special, bos_id, eos_id
+        self._h = lib().tk_oracle_new(_p(blob, ctypes.c_uint8), _p(offs, ctypes.c_uint32), len(self.tokens),
+                                      num_special, bos_id, eos_id)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tk_oracle_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def encode(self, text: bytes, add_bos=False, add_eos=False):
+        n = len(text)
+        buf = np.frombuffer(text, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+        out = np.zeros(n + 2, np.uint32)
+        k = lib().tk_oracle_encode(self._h, _p(buf, ctypes.c_uint8), n, int(add_bos), int(add_eos),
+                                   _p(out, ctypes.c_uint32), n + 2)
+        return out[:k].tolist()
+
+    def encode_batch(self, data: np.ndarray, offs: np.ndarray, add_bos=True, add_eos=True, threads=1):
+        """data: uint8[n_bytes], offs: uint64[D+1] -> (ids uint32[T], out_offs uint64[D+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        D = len(offs) - 1
+        n = int(offs[-1])
+        dbuf = data if n else np.zeros(1, np.uint8)
+        out = np.zeros(n + 2 * D + 1, np.uint32)
+        oo = np.zeros(D + 1, np.uint64)
+        t = lib().tk_oracle_encode_batch(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), D,
+                                         int(add_bos), int(add_eos), _p(out, ctypes.c_uint32),
+                                         _p(oo, ctypes.c_uint64), threads)
+        return out[:t].copy(), oo
+
+
+def fnv1a(ids: np.ndarray) -> int:
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    if len(ids) == 0:
+        ids_p = np.zeros(1, np.uint32)
+        return lib().tk_oracle_fnv1a(_p(ids_p, ctypes.c_uint32), 0)
+    return lib().tk_oracle_fnv1a(_p(ids, ctypes.c_uint32), len(ids))

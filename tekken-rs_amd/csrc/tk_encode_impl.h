@@ -1,0 +1,640 @@
+// tk_encode_impl.h -- the wave-level tokenization algorithm (split + lookup + merge + emit).
+//
+// This is the device code of the hot path named by BASELINE.json: what the reference does in
+//   CoreBPE::encode(text, {})              reference src/tekkenizer.rs:384-386
+//   token += num_special_tokens            reference src/tekkenizer.rs:390-392
+//   BOS / EOS insertion                    reference src/tekkenizer.rs:394-402
+// re-designed for 64-wide CDNA4 wavefronts: one wave walks one document with a sliding
+// 64-byte window, ONE LANE PER BYTE.
+//
+//   1. load 64 bytes, classify every code point (ASCII by ALU, others via the class trie)
+//   2. wave ballots turn the classes into 64-bit masks; every lane decides locally whether a
+//      piece starts at its byte (the 7 alternatives of src/tekkenizer.rs:123 restated as
+//      local rules -- DESIGN.md "Split rules", modelled in tools/split_rules_model.py)
+//   3. the window commits up to its last start that no unseen byte can change
+//   4. each piece-start lane probes SHORT/LONG for the whole-piece shortcut
+//   5. pieces that miss are merged in place: lanes are parts, an `alive` ballot mask is the
+//      part list, the leftmost minimum-rank pair of every piece is found with a segmented
+//      min-scan over lanes and merged, one merge per piece per round (exactly the order of
+//      tiktoken's _byte_pair_merge); pair ranks come from PAIR2/PAIR
+//   6. surviving part heads are compacted with popcounts and written as final ids
+//
+// Pieces that do not fit a window (>~60 bytes) take tk_long_piece(): sequential end search,
+// wave-wide polynomial hash, LONG probe, and -- only in the second pass, which owns scratch
+// memory -- a wave-cooperative merge with block minima.
+//
+// The file is included with a set of wave primitives already defined (wv_lane, wv_ballot,
+// wv_shfl, wv_up1, wv_dn1, wv_sync, wv_atomic_add, TK_DEV): tk_wave_hip.h for gfx950, and a
+// fiber emulator in tests/emu/ that lets the CPU test-suite run this very source.
+#ifndef TK_ENCODE_IMPL_H
+#define TK_ENCODE_IMPL_H
+#include <stdint.h>
+
+#include "tk_encode_impl_args.h"
+
+#define TK_CLS_O 0u
+#define TK_CLS_L 1u
+#define TK_CLS_N 2u
+#define TK_CLS_S 3u
+#define TK_DEAD 0xFFFFFFFFu
+#define TK_NONE 0xFFFFFFFFu
+#define TK_DOC_CHUNK 8u /* documents taken per work-queue fetch */
+
+
+struct TkPolyPow {  // per-lane powers of the two polynomial bases
+    uint32_t pw1, ipw1, pw2, ipw2;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+TK_DEV uint64_t tk_lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+TK_DEV int tk_ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+TK_DEV int tk_msb64(uint64_t x) { return x ? 63 - __builtin_clzll(x) : 0; }
+TK_DEV bool tk_bit(uint64_t m, int i) { return (m >> i) & 1ull; }
+TK_DEV int tk_popc64(uint64_t x) { return __builtin_popcountll(x); }
+
+TK_DEV uint32_t tk_ascii_class(uint32_t b) {
+    if (((b | 0x20u) - 0x61u) < 26u) return TK_CLS_L;
+    if ((b - 0x30u) < 10u) return TK_CLS_N;
+    if ((b - 9u) < 5u || b == 0x20u) return TK_CLS_S;
+    return TK_CLS_O;
+}
+
+TK_DEV uint32_t tk_uc_class(const TkTablesView& t, uint32_t cp) {
+    if (cp >= 0x110000u) return TK_CLS_O;
+    uint32_t blk = t.uc_stage1[cp >> 7];
+    uint32_t w = t.uc_stage2[blk * 8u + ((cp & 127u) >> 4)];
+    return (w >> (2u * (cp & 15u))) & 3u;
+}
+
+TK_DEV uint32_t tk_probe_short(const TkTablesView& t, uint32_t lo, uint32_t hi, uint32_t len) {
+    uint32_t s = tk_short_hash(lo, hi, len) & t.short_mask;
+    for (;;) {
+        tk_short_entry e = t.short_tab[s];
+        if (e.len == 0u) return TK_RANK_MAX;
+        if (e.len == len && e.key_lo == lo && e.key_hi == hi) return e.rank;
+        s = (s + 1u) & t.short_mask;
+    }
+}
+
+// text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so
+// that the result is exact, not probabilistic.
+TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, uint32_t len, const uint8_t* text) {
+    uint32_t s = tk_long_hash(h1, len) & t.long_mask;
+    for (;;) {
+        tk_long_entry e = t.long_tab[s];
+        if (e.len == 0u) return TK_RANK_MAX;
+        if (e.len == len && e.tag == h2) {
+            const uint8_t* q = t.blob + e.blob_off;
+            uint32_t k = 0;
+            while (k < len && q[k] == text[k]) ++k;
+            if (k == len) return e.rank;
+        }
+        s = (s + 1u) & t.long_mask;
+    }
+}
+
+TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
+    uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
+    uint32_t s = tk_pair_hash(a, b) & t.pair_mask;
+    for (;;) {
+        uint64_t e = t.pair_tab[s];
+        if (e == TK_PAIR_EMPTY) return TK_RANK_MAX;
+        if (tk_pair_key(e) == key) return tk_pair_rank(e);
+        s = (s + 1u) & t.pair_mask;
+    }
+}
+
+TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, lane ^ d);
+    return v;
+}
+
+TK_DEV uint64_t tk_wave_min64(uint64_t v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = wv_shfl((uint32_t)v, lane ^ d);
+        uint32_t hi = wv_shfl((uint32_t)(v >> 32), lane ^ d);
+        uint64_t o = ((uint64_t)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+TK_DEV TkPolyPow tk_poly_pow(const TkTablesView& t, int lane) {
+    TkPolyPow p;
+    p.pw1 = 1u; p.ipw1 = 1u; p.pw2 = 1u; p.ipw2 = 1u;
+    for (int i = 0; i < lane; ++i) {
+        p.pw1 *= TK_POLY_P1; p.ipw1 *= t.p1inv;
+        p.pw2 *= TK_POLY_P2; p.ipw2 *= t.p2inv;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// sequential matcher used only by the long-piece path: end of the match that starts at `pos`
+// (a piece start) in the document [.., s1).  Same alternatives, same order as
+// src/tekkenizer.rs:123.  Every lane computes the same value.
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tk_decode_at(const uint8_t* b, uint64_t p, uint64_t n, uint32_t* len) {
+    uint32_t b0 = b[p];
+    if (b0 < 0x80u) { *len = 1; return b0; }
+    if ((b0 & 0xE0u) == 0xC0u && p + 1 < n && (b[p + 1] & 0xC0u) == 0x80u) {
+        *len = 2; return ((b0 & 0x1Fu) << 6) | (b[p + 1] & 0x3Fu);
+    }
+    if ((b0 & 0xF0u) == 0xE0u && p + 2 < n && (b[p + 1] & 0xC0u) == 0x80u && (b[p + 2] & 0xC0u) == 0x80u) {
+        *len = 3; return ((b0 & 0x0Fu) << 12) | ((uint32_t)(b[p + 1] & 0x3Fu) << 6) | (b[p + 2] & 0x3Fu);
+    }
+    if ((b0 & 0xF8u) == 0xF0u && p + 3 < n && (b[p + 1] & 0xC0u) == 0x80u && (b[p + 2] & 0xC0u) == 0x80u &&
+        (b[p + 3] & 0xC0u) == 0x80u) {
+        *len = 4;
+        return ((b0 & 0x07u) << 18) | ((uint32_t)(b[p + 1] & 0x3Fu) << 12) | ((uint32_t)(b[p + 2] & 0x3Fu) << 6) |
+               (b[p + 3] & 0x3Fu);
+    }
+    *len = 1;
+    return 0xFFFFFFFFu;
+}
+
+TK_DEV uint32_t tk_class_at(const TkTablesView& t, const uint8_t* b, uint64_t p, uint64_t n, uint32_t* len,
+                            uint32_t* cp) {
+    uint32_t c = tk_decode_at(b, p, n, len);
+    *cp = c;
+    if (c < 0x80u) return tk_ascii_class(c);
+    return tk_uc_class(t, c);
+}
+
+TK_DEV uint32_t tk_fold(uint32_t cp) {
+    if (cp >= 'A' && cp <= 'Z') return cp + 32u;
+    if (cp == 0x17Fu) return 's';
+    return cp;
+}
+
+TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t pos, uint64_t n) {
+    uint32_t l0, l1, l2, c0, c1, c2;
+    uint32_t k0 = tk_class_at(t, b, pos, n, &l0, &c0);
+    if (c0 == '\'' && pos + 1 < n) {  // alt 1
+        (void)tk_class_at(t, b, pos + 1, n, &l1, &c1);
+        uint32_t f1 = tk_fold(c1);
+        if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') return pos + 1 + l1;
+        if ((f1 == 'r' || f1 == 'v' || f1 == 'l') && pos + 1 + l1 < n) {
+            (void)tk_class_at(t, b, pos + 1 + l1, n, &l2, &c2);
+            uint32_t f2 = tk_fold(c2);
+            if (((f1 == 'r' || f1 == 'v') && f2 == 'e') || (f1 == 'l' && f2 == 'l')) return pos + 1 + l1 + l2;
+        }
+    }
+    {  // alt 2
+        bool crlf = (c0 == '\r' || c0 == '\n');
+        bool with_prefix = !(crlf || k0 == TK_CLS_L || k0 == TK_CLS_N);
+        for (int attempt = with_prefix ? 0 : 1; attempt < 2; ++attempt) {
+            uint64_t p = attempt == 0 ? pos + l0 : pos;
+            uint64_t q = p;
+            while (q < n) {
+                uint32_t l, c;
+                if (tk_class_at(t, b, q, n, &l, &c) != TK_CLS_L) break;
+                q += l;
+            }
+            if (q > p) return q;
+        }
+    }
+    if (k0 == TK_CLS_N) {  // alt 3
+        uint64_t q = pos + l0;
+        for (int cnt = 1; cnt < 3 && q < n; ++cnt) {
+            uint32_t l, c;
+            if (tk_class_at(t, b, q, n, &l, &c) != TK_CLS_N) break;
+            q += l;
+        }
+        return q;
+    }
+    for (int attempt = (c0 == ' ') ? 0 : 1; attempt < 2; ++attempt) {  // alt 4
+        uint64_t p = attempt == 0 ? pos + 1 : pos;
+        uint64_t q = p;
+        while (q < n) {
+            uint32_t l, c;
+            if (tk_class_at(t, b, q, n, &l, &c) != TK_CLS_O) break;
+            q += l;
+        }
+        if (q > p) {
+            while (q < n && (b[q] == '\r' || b[q] == '\n')) ++q;
+            return q;
+        }
+    }
+    // alts 5-7 over the maximal white-space run
+    uint64_t e = pos, after_last_nl = 0, last_char = pos;
+    bool has_nl = false;
+    while (e < n) {
+        uint32_t l, c;
+        if (tk_class_at(t, b, e, n, &l, &c) != TK_CLS_S) break;
+        last_char = e;
+        e += l;
+        if (c == '\r' || c == '\n') { has_nl = true; after_last_nl = e; }
+    }
+    if (has_nl) return after_last_nl;
+    if (e == n) return e;
+    if (last_char > pos) return last_char;
+    return e > pos ? e : pos + l0;
+}
+
+// ------------------------------------------------------------------------------------------
+// long piece: [w0, e) does not fit a window.  Returns false if the document must be deferred
+// to the second pass (a miss that needs scratch memory and HAS_SCRATCH is false).
+// ------------------------------------------------------------------------------------------
+template <bool HAS_SCRATCH>
+TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e,
+                          uint32_t* out, uint32_t& cursor, uint32_t* scratch) {
+    const TkTablesView& t = a.t;
+    const uint64_t n = e - w0;
+    uint32_t r = TK_RANK_MAX;
+    if (n == 1) {
+        r = a.bytes[w0];
+    } else if (n <= 8) {
+        uint64_t key = 0;
+        for (uint64_t k = 0; k < n; ++k) key |= (uint64_t)a.bytes[w0 + k] << (8 * k);
+        r = tk_probe_short(t, (uint32_t)key, (uint32_t)(key >> 32), (uint32_t)n);
+    } else {
+        // H = sum b_j P^(n-1-j), folded 64 bytes at a time: H = H * P^m + (sum b_i P^-i) * P^(m-1)
+        uint32_t h1 = 0, h2 = 0;
+        for (uint64_t c = w0; c < e; c += 64) {
+            int m = (e - c) < 64 ? (int)(e - c) : 64;
+            uint32_t bb = lane < m ? (uint32_t)a.bytes[c + lane] : 0u;
+            uint32_t s1 = tk_wave_sum(bb * pw.ipw1, lane);
+            uint32_t s2 = tk_wave_sum(bb * pw.ipw2, lane);
+            uint32_t pm1 = wv_shfl(pw.pw1, m - 1), pm2 = wv_shfl(pw.pw2, m - 1);
+            h1 = h1 * (pm1 * TK_POLY_P1) + s1 * pm1;
+            h2 = h2 * (pm2 * TK_POLY_P2) + s2 * pm2;
+        }
+        r = tk_probe_long(t, h1, h2, (uint32_t)n, a.bytes + w0);
+    }
+    if (r != TK_RANK_MAX) {
+        if (lane == 0) out[cursor] = r + t.num_special;
+        cursor += 1;
+        return true;
+    }
+    if (!HAS_SCRATCH) return false;
+
+    // ---- wave-cooperative merge over scratch: tok | prk | nxt | prv | bmin(u64) ----
+    const uint32_t nn = (uint32_t)n;
+    const uint32_t nb = (nn + 63u) / 64u;
+    uint32_t* tok = scratch;
+    uint32_t* prk = tok + nn;
+    uint32_t* nxt = prk + nn;
+    uint32_t* prv = nxt + nn;
+    uint32_t* bmin = prv + nn;  // 2 words per block: lo = position, hi = rank
+    for (uint32_t i = (uint32_t)lane; i < nn; i += 64u) {
+        uint32_t b0 = a.bytes[w0 + i];
+        uint32_t b1 = (i + 1u < nn) ? (uint32_t)a.bytes[w0 + i + 1u] : 0u;
+        tok[i] = b0;
+        prk[i] = (i + 1u < nn) ? t.pair2[b0 | (b1 << 8)] : TK_RANK_MAX;
+        nxt[i] = i + 1u;
+        prv[i] = i ? i - 1u : TK_NONE;
+    }
+    wv_sync();
+    for (uint32_t blk = 0; blk < nb; ++blk) {
+        uint32_t i = blk * 64u + (uint32_t)lane;
+        uint32_t rk = i < nn ? prk[i] : TK_RANK_MAX;
+        uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | i);
+        uint64_t m = tk_wave_min64(key, lane);
+        if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
+    }
+    wv_sync();
+    for (;;) {
+        uint64_t best = ~0ull;
+        for (uint32_t bq = (uint32_t)lane; bq < nb; bq += 64u) {
+            uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
+            best = v < best ? v : best;
+        }
+        best = tk_wave_min64(best, lane);
+        if (best == ~0ull) break;
+        const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
+        const uint32_t j = nxt[i];
+        const uint32_t k = nxt[j];
+        const uint32_t p = prv[i];
+        const uint32_t new_i = (k < nn) ? tk_probe_pair(t, rr, tok[k]) : TK_RANK_MAX;
+        const uint32_t new_p = (p != TK_NONE) ? tk_probe_pair(t, tok[p], rr) : TK_RANK_MAX;
+        wv_sync();
+        if (lane == 0) {
+            tok[i] = rr; tok[j] = TK_DEAD; prk[j] = TK_RANK_MAX; nxt[i] = k;
+            if (k < nn) prv[k] = i;
+            prk[i] = new_i;
+            if (p != TK_NONE) prk[p] = new_p;
+        }
+        wv_sync();
+        uint32_t blks[3] = {i / 64u, j / 64u, (p != TK_NONE) ? p / 64u : i / 64u};
+        for (int q = 0; q < 3; ++q) {
+            if (q == 1 && blks[1] == blks[0]) continue;
+            if (q == 2 && (blks[2] == blks[0] || blks[2] == blks[1])) continue;
+            uint32_t x = blks[q] * 64u + (uint32_t)lane;
+            uint32_t rk = x < nn ? prk[x] : TK_RANK_MAX;
+            uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
+            uint64_t m = tk_wave_min64(key, lane);
+            if (lane == 0) { bmin[2 * blks[q]] = (uint32_t)m; bmin[2 * blks[q] + 1] = (uint32_t)(m >> 32); }
+        }
+        wv_sync();
+    }
+    for (uint32_t blk = 0; blk < nb; ++blk) {
+        uint32_t i = blk * 64u + (uint32_t)lane;
+        uint32_t tv = i < nn ? tok[i] : TK_DEAD;
+        uint64_t am = wv_ballot(tv != TK_DEAD);
+        if (tv != TK_DEAD) out[cursor + (uint32_t)tk_popc64(am & tk_lowmask(lane))] = tv + t.num_special;
+        cursor += (uint32_t)tk_popc64(am);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// one document
+// ------------------------------------------------------------------------------------------
+template <bool HAS_SCRATCH>
+TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkPolyPow& pw, uint32_t* scratch) {
+    const TkTablesView& t = a.t;
+    const uint64_t s0 = a.doc_offs[d], s1 = a.doc_offs[d + 1];
+    uint32_t* out = a.staging + s0 + 2 * d;
+    uint32_t cursor = 0;
+    if (a.add_bos) {
+        if (lane == 0) out[0] = t.bos_id;
+        cursor = 1;
+    }
+    uint64_t w0 = s0;
+    while (w0 < s1) {
+        const uint64_t rem = s1 - w0;
+        int nv = rem < 64 ? (int)rem : 64;
+        const bool at_end = rem <= 64;
+
+        // ---- 1. load + classify ---------------------------------------------------------
+        uint32_t b0 = lane < nv ? (uint32_t)a.bytes[w0 + lane] : 0u;
+        if (!at_end) {
+            // a char cut by the window end has an unknown class: leave it to the next window
+            uint32_t nominal = b0 < 0xC0u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : b0 < 0xF8u ? 4u : 1u;
+            uint64_t csraw = wv_ballot(lane < nv && ((b0 & 0xC0u) != 0x80u || lane == 0));
+            int last = tk_msb64(csraw);
+            uint32_t nl = wv_shfl(nominal, last);
+            if (last + (int)nl > nv && last > 0) nv = last;
+            if (lane >= nv) b0 = 0u;
+        }
+        const bool valid = lane < nv;
+        const uint32_t b1 = wv_up1(b0), b2 = wv_up1(b1), b3 = wv_up1(b2);
+        const bool lead = (b0 & 0xC0u) != 0x80u || lane == 0;
+        uint32_t cls = TK_CLS_O, clen = 1;
+        if (b0 < 0x80u) {
+            cls = tk_ascii_class(b0);
+        } else if (lead && b0 >= 0xC0u) {
+            uint32_t cp = 0xFFFFFFFFu;
+            if (b0 < 0xE0u) {
+                if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
+            } else if (b0 < 0xF0u) {
+                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
+                    cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
+                }
+            } else if (b0 < 0xF8u) {
+                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
+                    cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
+                }
+            }
+            if (cp != 0xFFFFFFFFu) cls = tk_uc_class(t, cp);
+        }
+        const uint64_t CS = wv_ballot(valid && lead);
+        {
+            // continuation bytes take the class of their lead byte so that runs are contiguous
+            const uint32_t c1 = wv_dn1(cls), c2 = wv_dn1(c1), c3 = wv_dn1(c2);
+            if (!lead) {
+                int dist = lane - tk_msb64(CS & tk_lowmask(lane));
+                cls = dist == 1 ? c1 : dist == 2 ? c2 : dist == 3 ? c3 : TK_CLS_O;
+            }
+        }
+        const uint64_t mL = wv_ballot(valid && cls == TK_CLS_L);
+        const uint64_t mN = wv_ballot(valid && cls == TK_CLS_N);
+        const uint64_t mS = wv_ballot(valid && cls == TK_CLS_S);
+        const uint64_t mO = wv_ballot(valid && cls == TK_CLS_O);
+        const uint64_t NLm = wv_ballot(valid && (b0 == 10u || b0 == 13u));
+        const uint64_t SPm = wv_ballot(valid && b0 == 0x20u);
+
+        // ---- 2. local piece-start rules ---------------------------------------------------
+        // alt 1 (?i:'s|'t|'re|'ve|'m|'ll|'d): fires only where a match starts at the apostrophe
+        uint32_t ce = 0;
+        if (b0 == 0x27u) {
+            const uint32_t f1 = b1 | 0x20u, f2 = b2 | 0x20u;
+            if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') ce = 2;
+            else if (b1 == 0xC5u && b2 == 0xBFu) ce = 3;  // U+017F folds to 's'
+            else if (((f1 == 'r' || f1 == 'v') && f2 == 'e') || (f1 == 'l' && f2 == 'l')) ce = 3;
+        }
+        const bool fire = ce && (lane == 0 || (!tk_bit(mO, lane - 1) && !tk_bit(SPm, lane - 1)));
+        const uint64_t F2 = wv_ballot(valid && fire && ce == 2);
+        const uint64_t F3 = wv_ballot(valid && fire && ce == 3);
+        const uint64_t CEND = (F2 << 2) | (F3 << 3);
+        // CR/LF absorbed by alt 4's trailing [\r\n]*: leading CR/LF of a white-space run that
+        // directly follows a class-O byte (carry ripple through the CR/LF run)
+        const uint64_t seeds = NLm & (mO << 1);
+        const uint64_t ABS = ((NLm + seeds) ^ NLm) & NLm;
+        const uint64_t SPR = mS & ~ABS;  // effective white space
+        const uint64_t Nst = mN & ~(mN << 1);
+
+        bool st = false, unc = false;
+        if (valid && lead) {
+            if (lane == 0) {
+                st = true;
+            } else {
+                const int pm = lane - 1;
+                const bool pL = tk_bit(mL, pm), pN = tk_bit(mN, pm), pS = tk_bit(mS, pm), pO = tk_bit(mO, pm);
+                if (cls == TK_CLS_L) {
+                    if (pL) st = tk_bit(CEND, lane);             // only right after a contraction
+                    else if (pN) st = true;
+                    else if (pS) st = tk_bit(NLm, pm);           // other white space is alt 2's prefix
+                    else {
+                        const int qs = tk_msb64(CS & tk_lowmask(lane));
+                        const bool runstart = qs == 0 || !tk_bit(mO, qs - 1);
+                        st = !runstart || (qs > 0 && tk_bit(SPm, qs - 1));
+                    }
+                } else if (cls == TK_CLS_N) {
+                    if (!pN) st = true;
+                    else {
+                        const int rs = tk_msb64(Nst & tk_lowmask(lane + 1));
+                        const int k = tk_popc64(CS & tk_lowmask(lane) & ~tk_lowmask(rs));
+                        st = (k % 3) == 0;                       // \p{N}{1,3}
+                    }
+                } else if (cls == TK_CLS_O) {
+                    st = !pO && !tk_bit(SPm, pm);                // ' ?' of alt 4 takes one U+0020
+                } else {
+                    (void)pS;
+                    if (tk_bit(ABS, lane)) st = false;
+                    else if (!tk_bit(SPR, pm)) st = true;        // start of the effective run
+                    else {
+                        const uint64_t x = SPR >> lane;
+                        const int rl = tk_ctz64(~x);
+                        const int e = lane + rl;
+                        if (!at_end && e >= nv) unc = true;      // run reaches unseen bytes
+                        else {
+                            const bool later_nl = ((NLm >> lane) & tk_lowmask(rl)) != 0;
+                            if (later_nl) st = false;            // inside \s*[\r\n]+
+                            else if (tk_bit(NLm, pm)) st = true; // first char after the last CR/LF
+                            else st = (lane + (int)clen == e) && (e < nv);  // \s+(?!\S) leaves the last char
+                        }
+                    }
+                }
+            }
+        }
+        const uint64_t PS = wv_ballot(st);
+        const uint64_t UNC = wv_ballot(unc);
+
+        // ---- 3. how far may this window commit? -------------------------------------------
+        int region_end;
+        uint64_t PSp;
+        if (at_end) {
+            region_end = nv;
+            PSp = PS;
+        } else {
+            const int fu = UNC ? tk_ctz64(UNC) : nv;
+            const uint64_t cert = PS & tk_lowmask(fu);
+            const int estar = tk_msb64(cert);
+            if (estar == 0) {
+                // the first piece does not end inside the window
+                const uint64_t e = tk_match_end(t, a.bytes, w0, s1);
+                if (a.dbg_starts) {
+                    for (uint64_t q = w0 + (uint64_t)lane; q < e; q += 64) a.dbg_starts[q] = (q == w0);
+                }
+                if (!a.split_only) {
+                    if (!tk_long_piece<HAS_SCRATCH>(a, pw, lane, w0, e, out, cursor, scratch)) return false;
+                }
+                w0 = e;
+                continue;
+            }
+            region_end = estar;
+            PSp = cert & ~(1ull << estar);
+        }
+        const bool inreg = lane < region_end;
+        if (a.dbg_starts && inreg) a.dbg_starts[w0 + lane] = tk_bit(PSp, lane);
+        if (a.split_only) {
+            w0 += (uint64_t)region_end;
+            continue;
+        }
+
+        // ---- 4. whole-piece lookup ----------------------------------------------------------
+        const uint64_t E = PSp | (region_end < 64 ? (1ull << region_end) : 0ull);
+        const int ps = tk_msb64(PSp & tk_lowmask(lane + 1));
+        int pe;
+        {
+            const uint64_t y = lane < 63 ? (E >> (lane + 1)) : 0ull;
+            pe = y ? lane + 1 + tk_ctz64(y) : 64;
+        }
+        const bool isstart = inreg && tk_bit(PSp, lane);
+        const int len = pe - lane;
+        const uint32_t d4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        uint32_t d4hi = wv_shfl(d4, lane + 4 < 64 ? lane + 4 : lane);
+        if (lane + 4 >= 64) d4hi = 0u;
+
+        uint32_t h1 = 0, h2 = 0;
+        const uint64_t LONGM = wv_ballot(isstart && len >= 9);
+        if (LONGM) {
+            const uint32_t t1 = b0 * pw.ipw1, t2 = b0 * pw.ipw2;
+            uint32_t f1 = t1, f2 = t2;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o1 = wv_shfl(f1, lane >= dd ? lane - dd : lane);
+                const uint32_t o2 = wv_shfl(f2, lane >= dd ? lane - dd : lane);
+                if (lane >= dd) { f1 += o1; f2 += o2; }
+            }
+            const int el = pe - 1;
+            const uint32_t fe1 = wv_shfl(f1, el), fe2 = wv_shfl(f2, el);
+            const uint32_t pe1 = wv_shfl(pw.pw1, el), pe2 = wv_shfl(pw.pw2, el);
+            h1 = (fe1 - (f1 - t1)) * pe1;
+            h2 = (fe2 - (f2 - t2)) * pe2;
+        }
+
+        uint32_t tokv = TK_RANK_MAX;
+        if (isstart) {
+            if (len == 1) {
+                tokv = b0;  // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
+            } else if (len <= 8) {
+                uint32_t lo = d4, hi = d4hi;
+                if (len <= 4) { hi = 0u; if (len < 4) lo &= (1u << (8 * len)) - 1u; }
+                else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
+                tokv = tk_probe_short(t, lo, hi, (uint32_t)len);
+            } else {
+                tokv = tk_probe_long(t, h1, h2, (uint32_t)len, a.bytes + w0 + lane);
+            }
+        }
+        const uint64_t Hm = wv_ballot(isstart && tokv != TK_RANK_MAX);
+        const uint64_t Mi = PSp & ~Hm;
+
+        // ---- 5. in-window byte-pair merge for the pieces that missed ------------------------
+        uint64_t A = 0;
+        uint32_t tok = b0;
+        const bool inmiss = inreg && tk_bit(Mi, ps);
+        if (Mi) {
+            A = wv_ballot(inmiss);
+            uint32_t prank = TK_RANK_MAX;
+            if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
+            const int sl = pe - 1 < 63 ? pe - 1 : 63;
+            for (;;) {
+                const uint32_t key = prank == TK_RANK_MAX ? 0xFFFFFFFFu : ((prank << 6) | (uint32_t)lane);
+                uint32_t m = key;
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t o = wv_shfl(m, lane >= dd ? lane - dd : lane);
+                    if (lane >= dd && lane - dd >= ps) m = o < m ? o : m;
+                }
+                const uint32_t segmin = wv_shfl(m, sl);
+                const bool winner = inmiss && key != 0xFFFFFFFFu && key == segmin;
+                const uint64_t W = wv_ballot(winner);
+                if (!W) break;
+                const bool alive = tk_bit(A, lane);
+                const uint64_t below = A & tk_lowmask(lane);
+                const bool dead = alive && below && tk_bit(W, tk_msb64(below));
+                const uint64_t Dm = wv_ballot(dead);
+                A &= ~Dm;
+                if (winner) tok = prank;          // merged token id == rank of the pair
+                if (dead) prank = TK_RANK_MAX;
+                const uint64_t z = lane < 63 ? (A >> (lane + 1)) : 0ull;
+                const int na = z ? lane + 1 + tk_ctz64(z) : 64;
+                const bool has_next = na < pe;
+                const uint32_t tn = wv_shfl(tok, na < 64 ? na : lane);
+                const bool need = tk_bit(A, lane) && (winner || (has_next && tk_bit(W, na)));
+                if (need) prank = has_next ? tk_probe_pair(t, tok, tn) : TK_RANK_MAX;
+            }
+        }
+
+        // ---- 6. emit --------------------------------------------------------------------------
+        const bool hitstart = isstart && tokv != TK_RANK_MAX;
+        const bool istok = hitstart || (inmiss && tk_bit(A, lane));
+        const uint64_t Tm = wv_ballot(istok);
+        if (istok) {
+            out[cursor + (uint32_t)tk_popc64(Tm & tk_lowmask(lane))] = (hitstart ? tokv : tok) + t.num_special;
+        }
+        cursor += (uint32_t)tk_popc64(Tm);
+        w0 += (uint64_t)region_end;
+    }
+    if (!a.split_only) {
+        if (a.add_eos) {
+            if (lane == 0) out[cursor] = t.eos_id;
+            cursor += 1;
+        }
+        if (lane == 0) a.counts[d] = cursor;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// one wave: pull documents from the work queue until it is empty
+// ------------------------------------------------------------------------------------------
+template <bool HAS_SCRATCH>
+TK_DEV void tk_encode_wave(const TkEncodeArgs& a, int lane, uint64_t wave_id) {
+    const TkPolyPow pw = tk_poly_pow(a.t, lane);
+    uint32_t* scratch = HAS_SCRATCH ? a.scratch + wave_id * a.scratch_words_per_wave : nullptr;
+    const uint64_t total = HAS_SCRATCH ? (uint64_t)a.n_todo : a.n_docs;
+    const uint32_t chunk = HAS_SCRATCH ? 1u : TK_DOC_CHUNK;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = wv_atomic_add(a.work_counter, chunk);
+        base = wv_shfl(base, 0);
+        if ((uint64_t)base >= total) break;
+        const uint64_t hi = (uint64_t)base + chunk < total ? (uint64_t)base + chunk : total;
+        for (uint64_t q = base; q < hi; ++q) {
+            const uint64_t d = HAS_SCRATCH ? (uint64_t)a.todo_list[q] : q;
+            const bool ok = tk_encode_doc<HAS_SCRATCH>(a, d, lane, pw, scratch);
+            if (!ok && lane == 0) {
+                // pass 1 only: the document needs the scratch-backed merge
+                a.counts[d] = 0;
+                const uint32_t slot = wv_atomic_add(a.defer_count, 1u);
+                a.defer_list[slot] = (uint32_t)d;
+            }
+        }
+    }
+}
+
+#endif

@@ -1,0 +1,28 @@
+// tk_encode_impl_args.h -- argument block of the encode kernels (host + device view).
+#ifndef TK_ENCODE_IMPL_ARGS_H
+#define TK_ENCODE_IMPL_ARGS_H
+#include <stdint.h>
+
+#include "tk_hash.h"
+#include "tk_tables.h"
+
+struct TkEncodeArgs {
+    const uint8_t* bytes;       // packed text of all documents
+    const uint64_t* doc_offs;   // [n_docs + 1]
+    uint64_t n_docs;
+    uint32_t* staging;          // [n_bytes + 2*n_docs]: doc d writes from doc_offs[d] + 2*d
+    uint32_t* counts;           // [n_docs] ids produced per document
+    uint32_t* work_counter;     // dynamic work queue head
+    uint32_t* defer_list;       // pass 1: documents handed to pass 2
+    uint32_t* defer_count;
+    const uint32_t* todo_list;  // pass 2: the documents to process
+    uint32_t n_todo;
+    uint8_t* dbg_starts;        // optional: per-byte piece-start flags (tk_split_batch)
+    uint32_t* scratch;          // pass 2: per-wave scratch for the cooperative merge
+    uint64_t scratch_words_per_wave;
+    int add_bos, add_eos;
+    int split_only;
+    TkTablesView t;
+};
+
+#endif

@@ -1,0 +1,66 @@
+// tk_hash.h -- hash functions and table-entry layouts shared by the host table builder
+// (tk_tables.cpp) and the gfx950 kernels (tk_encode_impl.h).  Integer-only.
+//
+// Three lookup structures replace the FxHashMap<Vec<u8>,u32> that the reference hands to
+// CoreBPE::new (reference src/tekkenizer.rs:118-126, built at :776-816):
+//
+//   SHORT  piece bytes (2..8 bytes, exact 64-bit key + length)          -> rank
+//   LONG   piece bytes (>= 9 bytes, polynomial hash, verified vs blob)   -> rank
+//   PAIR   (id(A), id(B))  ->  rank(bytes(A) ++ bytes(B))                
+//   PAIR2  direct 64K table for two single bytes                         -> rank
+//
+// SHORT/LONG serve the whole-piece shortcut, PAIR/PAIR2 serve the merge loop.
+#ifndef TK_HASH_H
+#define TK_HASH_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TK_HD __host__ __device__ __forceinline__
+#else
+#define TK_HD inline
+#endif
+
+#define TK_RANK_MAX 0xFFFFFFFFu
+#define TK_ID_BITS 21u                   /* ids < 2^21 so that (a,b,rank) packs into 63 bits */
+#define TK_MAX_RANKS (1u << TK_ID_BITS)
+#define TK_PAIR_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define TK_POLY_P1 0x01000193u           /* odd => invertible mod 2^32 */
+#define TK_POLY_P2 0x9E3779B1u
+
+struct tk_short_entry {                  /* 16 B, len == 0 <=> empty */
+    uint32_t key_lo, key_hi;             /* piece bytes little-endian, zero padded */
+    uint32_t rank;
+    uint32_t len;                        /* 2..8 */
+};
+
+struct tk_long_entry {                   /* 16 B, len == 0 <=> empty */
+    uint32_t tag;                        /* second polynomial hash */
+    uint32_t rank;
+    uint32_t len;                        /* >= 9 */
+    uint32_t blob_off;                   /* token bytes start in the blob */
+};
+
+TK_HD uint32_t tk_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+TK_HD uint32_t tk_short_hash(uint32_t lo, uint32_t hi, uint32_t len) {
+    return tk_fmix32(lo * 0x9E3779B1u + (hi ^ (len << 28)) * 0x85EBCA77u + len);
+}
+
+TK_HD uint32_t tk_long_hash(uint32_t h1, uint32_t len) {
+    return tk_fmix32(h1 + len * 0x9E3779B1u);
+}
+
+TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
+    return tk_fmix32(a * 0x9E3779B1u + b * 0x85EBCA77u + 0x165667B1u);
+}
+
+TK_HD uint64_t tk_pair_pack(uint32_t a, uint32_t b, uint32_t rank) {
+    return ((uint64_t)a << (2 * TK_ID_BITS)) | ((uint64_t)b << TK_ID_BITS) | (uint64_t)rank;
+}
+TK_HD uint64_t tk_pair_key(uint64_t e) { return e >> TK_ID_BITS; }
+TK_HD uint32_t tk_pair_rank(uint64_t e) { return (uint32_t)(e & ((1u << TK_ID_BITS) - 1u)); }
+
+#endif

@@ -1,0 +1,27 @@
+// tk_kernels.h -- host-callable launchers of the gfx950 kernels (tk_kernels.hip).
+#ifndef TK_KERNELS_H
+#define TK_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tk_encode_impl_args.h"
+
+// pass 1 (no scratch) / pass 2 (scratch-backed long-piece merge); n_waves = waves launched
+hipError_t tk_launch_encode(const TkEncodeArgs& args, bool pass2, uint32_t n_waves, hipStream_t s);
+
+// counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
+// ceil(n/2048)+1 u64.  offs[n] (= total) is also what the host reads back.
+hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s);
+
+// out_ids[out_offs[d] + k] = staging[doc_offs[d] + 2*d + k] for k < counts[d]
+hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, const uint32_t* counts,
+                             const uint64_t* out_offs, uint64_t n_docs, uint32_t* out_ids, hipStream_t s);
+
+// UTF-8 validation of every document; *d_bad receives the number of invalid documents
+hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
+                              hipStream_t s);
+
+// self-test of the wave primitives (DPP shifts, bpermute); writes 0 to *d_fail when all pass
+hipError_t tk_launch_wave_selftest(uint32_t* d_fail, hipStream_t s);
+
+#endif

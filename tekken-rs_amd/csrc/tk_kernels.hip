@@ -1,0 +1,224 @@
+// tk_kernels.hip -- gfx950 kernels of the batch tokenization path.
+//
+//   tk_encode_kernel<false>   pass 1: every document, one wave per document at a time
+//   tk_encode_kernel<true>    pass 2: the few documents whose long pieces need scratch memory
+//   tk_scan_*                 per-document id counts -> output offsets (exclusive scan, u64)
+//   tk_compact_kernel         staging -> packed ids (the reference's Vec<u32> per document,
+//                             concatenated; ids already carry +num_special and BOS/EOS:
+//                             reference src/tekkenizer.rs:390-402)
+//   tk_validate_kernel        UTF-8 well-formedness per document (the &str invariant of
+//                             src/tekkenizer.rs:380 for callers that are not Rust)
+//
+// All integer / byte work: no MFMA.  Bound: HBM (see DESIGN.md for the byte accounting).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tk_kernels.h"
+#include "tk_wave_hip.h"
+#include "tk_encode_impl.h"
+
+#define TK_BLOCK 256
+
+template <bool HAS_SCRATCH>
+__global__ __launch_bounds__(TK_BLOCK) void tk_encode_kernel(TkEncodeArgs a) {
+    const int lane = wv_lane();
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
+    tk_encode_wave<HAS_SCRATCH>(a, lane, wave_id);
+}
+
+hipError_t tk_launch_encode(const TkEncodeArgs& args, bool pass2, uint32_t n_waves, hipStream_t s) {
+    const uint32_t blocks = (n_waves + (TK_BLOCK / 64) - 1) / (TK_BLOCK / 64);
+    if (blocks == 0) return hipSuccess;
+    if (pass2) hipLaunchKernelGGL(tk_encode_kernel<true>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    else hipLaunchKernelGGL(tk_encode_kernel<false>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of per-document counts (u32) into u64 offsets; 2048 counts per block
+// ------------------------------------------------------------------------------------------
+#define TK_SCAN_PER_THREAD 8
+#define TK_SCAN_TILE (TK_BLOCK * TK_SCAN_PER_THREAD)
+
+__device__ __forceinline__ uint64_t tk_block_exclusive_scan(uint64_t v, uint64_t* lds, uint64_t* total) {
+    // wave-level inclusive scan with DPP-free shuffles, then a scan over the 4 wave totals
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(x, d);
+        if (lane >= d) x += o;
+    }
+    if (lane == 63) lds[wid] = x;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (int w = 0; w < TK_BLOCK / 64; ++w) {
+        uint64_t s = lds[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_block_sums(const uint32_t* counts, uint64_t n, uint64_t* block_sums) {
+    __shared__ uint64_t lds[TK_BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * TK_SCAN_TILE + (uint64_t)threadIdx.x * TK_SCAN_PER_THREAD;
+    uint64_t v = 0;
+    for (int k = 0; k < TK_SCAN_PER_THREAD; ++k)
+        if (base + k < n) v += counts[base + k];
+    uint64_t tot;
+    (void)tk_block_exclusive_scan(v, lds, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_top(uint64_t* block_sums, uint64_t n_blocks) {
+    // single block: exclusive scan of block_sums in place; total at block_sums[n_blocks]
+    __shared__ uint64_t lds[TK_BLOCK / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n_blocks; base += TK_BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_blocks ? block_sums[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = tk_block_exclusive_scan(v, lds, &tot);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) block_sums[n_blocks] = carry;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_apply(const uint32_t* counts, uint64_t n, const uint64_t* block_sums,
+                                                          uint64_t n_blocks, uint64_t* offs) {
+    __shared__ uint64_t lds[TK_BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * TK_SCAN_TILE + (uint64_t)threadIdx.x * TK_SCAN_PER_THREAD;
+    uint32_t c[TK_SCAN_PER_THREAD];
+    uint64_t v = 0;
+    for (int k = 0; k < TK_SCAN_PER_THREAD; ++k) {
+        c[k] = (base + k < n) ? counts[base + k] : 0u;
+        v += c[k];
+    }
+    uint64_t tot;
+    uint64_t run = block_sums[blockIdx.x] + tk_block_exclusive_scan(v, lds, &tot);
+    for (int k = 0; k < TK_SCAN_PER_THREAD; ++k) {
+        if (base + k < n) offs[base + k] = run;
+        run += c[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) offs[n] = block_sums[n_blocks];
+}
+
+hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s) {
+    const uint64_t n_blocks = (n + TK_SCAN_TILE - 1) / TK_SCAN_TILE;
+    if (n_blocks == 0) {
+        return hipMemsetAsync(offs, 0, sizeof(uint64_t), s);
+    }
+    hipLaunchKernelGGL(tk_scan_block_sums, dim3((uint32_t)n_blocks), dim3(TK_BLOCK), 0, s, counts, n, block_sums);
+    hipLaunchKernelGGL(tk_scan_top, dim3(1), dim3(TK_BLOCK), 0, s, block_sums, n_blocks);
+    hipLaunchKernelGGL(tk_scan_apply, dim3((uint32_t)n_blocks), dim3(TK_BLOCK), 0, s, counts, n, block_sums, n_blocks,
+                       offs);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// compaction: one wave per document, grid-stride over documents
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TK_BLOCK) void tk_compact_kernel(const uint32_t* __restrict__ staging,
+                                                              const uint64_t* __restrict__ doc_offs,
+                                                              const uint32_t* __restrict__ counts,
+                                                              const uint64_t* __restrict__ out_offs, uint64_t n_docs,
+                                                              uint32_t* __restrict__ out_ids) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TK_BLOCK / 64);
+    for (uint64_t d = wave; d < n_docs; d += n_waves) {
+        const uint32_t cnt = counts[d];
+        const uint32_t* src = staging + doc_offs[d] + 2 * d;
+        uint32_t* dst = out_ids + out_offs[d];
+        for (uint32_t k = (uint32_t)lane; k < cnt; k += 64u) dst[k] = src[k];
+    }
+}
+
+hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, const uint32_t* counts,
+                             const uint64_t* out_offs, uint64_t n_docs, uint32_t* out_ids, hipStream_t s) {
+    if (n_docs == 0) return hipSuccess;
+    uint64_t blocks = (n_docs + (TK_BLOCK / 64) - 1) / (TK_BLOCK / 64);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(tk_compact_kernel, dim3((uint32_t)blocks), dim3(TK_BLOCK), 0, s, staging, doc_offs, counts,
+                       out_offs, n_docs, out_ids);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// UTF-8 validation (RFC 3629 well-formedness: no overlongs, no surrogates, <= U+10FFFF)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TK_BLOCK) void tk_validate_kernel(const uint8_t* __restrict__ bytes,
+                                                               const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
+                                                               uint32_t* bad) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TK_BLOCK / 64);
+    for (uint64_t d = wave; d < n_docs; d += n_waves) {
+        const uint64_t s0 = doc_offs[d], s1 = doc_offs[d + 1];
+        bool err = false;
+        for (uint64_t p = s0 + (uint64_t)lane; p < s1; p += 64) {
+            const uint32_t b0 = bytes[p];
+            if (b0 < 0x80u || (b0 & 0xC0u) == 0x80u) {
+                // a continuation byte must be preceded (within 3) by a lead that covers it
+                if ((b0 & 0xC0u) == 0x80u) {
+                    bool ok = false;
+                    for (uint32_t k = 1; k <= 3 && p >= s0 + k; ++k) {
+                        const uint32_t q = bytes[p - k];
+                        if ((q & 0xC0u) == 0x80u) continue;
+                        const uint32_t need = q >= 0xF0u ? 3u : q >= 0xE0u ? 2u : q >= 0xC0u ? 1u : 0u;
+                        ok = need >= k;
+                        break;
+                    }
+                    if (!ok) err = true;
+                }
+                continue;
+            }
+            const uint32_t need = b0 >= 0xF8u ? 99u : b0 >= 0xF0u ? 3u : b0 >= 0xE0u ? 2u : b0 >= 0xC2u ? 1u : 99u;
+            if (need == 99u || p + need >= s1) { err = true; continue; }  // bad lead or truncated
+            const uint32_t b1 = bytes[p + 1];
+            if ((b1 & 0xC0u) != 0x80u) { err = true; continue; }
+            if (need >= 2u && (bytes[p + 2] & 0xC0u) != 0x80u) { err = true; continue; }
+            if (need == 3u && (bytes[p + 3] & 0xC0u) != 0x80u) { err = true; continue; }
+            if (b0 == 0xE0u && b1 < 0xA0u) err = true;   // overlong 3-byte
+            if (b0 == 0xEDu && b1 >= 0xA0u) err = true;  // surrogates
+            if (b0 == 0xF0u && b1 < 0x90u) err = true;   // overlong 4-byte
+            if (b0 == 0xF4u && b1 >= 0x90u) err = true;  // > U+10FFFF
+            if (b0 > 0xF4u) err = true;
+        }
+        if (__ballot(err) && lane == 0) atomicAdd(bad, 1u);
+    }
+}
+
+hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
+                              hipStream_t s) {
+    if (n_docs == 0) return hipSuccess;
+    uint64_t blocks = (n_docs + (TK_BLOCK / 64) - 1) / (TK_BLOCK / 64);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(tk_validate_kernel, dim3((uint32_t)blocks), dim3(TK_BLOCK), 0, s, bytes, doc_offs, n_docs, d_bad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// self-test of the wave primitives (run once per context)
+// ------------------------------------------------------------------------------------------
+__global__ void tk_wave_selftest_kernel(uint32_t* fail) {
+    const int lane = wv_lane();
+    uint32_t v = 1000u + (uint32_t)lane;
+    uint32_t bad = 0;
+    const uint32_t up = wv_up1(v), dn = wv_dn1(v);
+    if (up != (lane < 63 ? v + 1u : 0u)) bad |= 1u;
+    if (dn != (lane > 0 ? v - 1u : 0u)) bad |= 2u;
+    if (wv_shfl(v, 63 - lane) != 1000u + (uint32_t)(63 - lane)) bad |= 4u;
+    if (wv_ballot((lane & 1) == 0) != 0x5555555555555555ull) bad |= 8u;
+    if (tk_wave_sum((uint32_t)lane, lane) != 2016u) bad |= 16u;
+    if (tk_wave_min64(((uint64_t)(100 - lane) << 32) | (uint32_t)lane, lane) != (((uint64_t)37 << 32) | 63u)) bad |= 32u;
+    if (bad) atomicOr(fail, bad);
+}
+
+hipError_t tk_launch_wave_selftest(uint32_t* d_fail, hipStream_t s) {
+    hipLaunchKernelGGL(tk_wave_selftest_kernel, dim3(1), dim3(64), 0, s, d_fail);
+    return hipGetLastError();
+}

@@ -1,0 +1,165 @@
+// tk_tables.cpp -- builds SHORT / LONG / PAIR / PAIR2 and the Unicode class trie image.
+// See tk_hash.h for the layouts and tk_tables.h for provenance.
+#include "tk_tables.h"
+
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+
+#include "../../include/tekken_hip.h"
+#include "unicode_tables.h"
+
+uint32_t tk_inverse_u32(uint32_t a) {
+    // Newton iteration for the inverse of an odd number modulo 2^32
+    uint32_t x = a;  // correct to 3 bits
+    for (int i = 0; i < 5; ++i) x *= 2u - a * x;
+    return x;
+}
+
+static uint32_t pow2_at_least(uint64_t n) {
+    uint32_t c = 1024;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+TkTablesView TkHostTables::host_view() const {
+    TkTablesView v;
+    v.uc_stage1 = uc_stage1.data();
+    v.uc_stage2 = uc_stage2.data();
+    v.short_tab = short_tab.data();
+    v.long_tab = long_tab.data();
+    v.pair_tab = pair_tab.data();
+    v.pair2 = pair2.data();
+    v.blob = blob.data();
+    v.short_mask = short_mask;
+    v.long_mask = long_mask;
+    v.pair_mask = pair_mask;
+    v.n_ranks = n_ranks;
+    v.num_special = num_special;
+    v.bos_id = bos_id;
+    v.eos_id = eos_id;
+    v.p1inv = p1inv;
+    v.p2inv = p2inv;
+    return v;
+}
+
+int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
+                    uint32_t bos_id, uint32_t eos_id, TkHostTables& out, std::string& err) {
+    if (!blob || !offs) { err = "null rank table"; return TK_ERR_INVALID_CONFIG; }
+    if (n_ranks < 256) {
+        err = "rank table must contain the 256 single-byte tokens (ranks 0..255)";
+        return TK_ERR_INVALID_CONFIG;
+    }
+    if (n_ranks >= TK_MAX_RANKS) {
+        err = "rank table too large: ids must fit in 21 bits";
+        return TK_ERR_INVALID_CONFIG;
+    }
+    if ((uint64_t)n_ranks + num_special >= 0xFFFFFFF0ull) { err = "id space overflow"; return TK_ERR_INVALID_CONFIG; }
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        if (offs[r + 1] < offs[r]) {
+            err = "token offsets must be non-decreasing (rank " + std::to_string(r) + ")";
+            return TK_ERR_INVALID_CONFIG;
+        }
+    }
+    // ranks < 256 must be the byte itself (reference src/tekkenizer.rs:793-798)
+    for (uint32_t r = 0; r < 256; ++r) {
+        if (offs[r + 1] - offs[r] != 1 || blob[offs[r]] != (uint8_t)r) {
+            err = "Expected byte token at rank " + std::to_string(r) + " to be [" + std::to_string(r) + "]";
+            return TK_ERR_INVALID_CONFIG;
+        }
+    }
+
+    out = TkHostTables();
+    out.n_ranks = n_ranks;
+    out.num_special = num_special;
+    out.bos_id = bos_id;
+    out.eos_id = eos_id;
+    out.p1inv = tk_inverse_u32(TK_POLY_P1);
+    out.p2inv = tk_inverse_u32(TK_POLY_P2);
+    out.offs.assign(offs, offs + n_ranks + 1);
+    out.blob.assign(blob, blob + offs[n_ranks]);
+    out.blob.resize(out.blob.size() + 16, 0);  // slack so verify loops never end on the last byte
+    out.uc_stage1.assign(TK_UC_STAGE1, TK_UC_STAGE1 + TK_UC_STAGE1_LEN);
+    out.uc_stage2.assign(TK_UC_STAGE2, TK_UC_STAGE2 + TK_UC_STAGE2_LEN);
+
+    // bytes -> rank; duplicate keys collapse in the reference's map and then fail its
+    // contiguity check (src/tekkenizer.rs:801-813) => reject here as well
+    std::unordered_map<std::string, uint32_t> by_bytes;
+    by_bytes.reserve((size_t)n_ranks * 2);
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        std::string k((const char*)blob + offs[r], offs[r + 1] - offs[r]);
+        if (!by_bytes.emplace(std::move(k), r).second) {
+            err = "Vocabulary ranks are not contiguous (duplicate token bytes at rank " + std::to_string(r) + ")";
+            return TK_ERR_INVALID_CONFIG;
+        }
+    }
+
+    uint64_t n_short = 0, n_long = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        uint32_t len = offs[r + 1] - offs[r];
+        if (len >= 2 && len <= 8) ++n_short;
+        else if (len >= 9) ++n_long;
+    }
+    out.n_short = n_short;
+    out.n_long = n_long;
+    uint32_t scap = pow2_at_least(2 * n_short + 1), lcap = pow2_at_least(2 * n_long + 1);
+    out.short_mask = scap - 1;
+    out.long_mask = lcap - 1;
+    out.short_tab.assign(scap, tk_short_entry{0, 0, 0, 0});
+    out.long_tab.assign(lcap, tk_long_entry{0, 0, 0, 0});
+    out.pair2.assign(65536, TK_RANK_MAX);
+
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const uint8_t* p = blob + offs[r];
+        uint32_t len = offs[r + 1] - offs[r];
+        if (len == 2) out.pair2[p[0] | ((uint32_t)p[1] << 8)] = r;
+        if (len >= 2 && len <= 8) {
+            uint64_t key = 0;
+            for (uint32_t k = 0; k < len; ++k) key |= (uint64_t)p[k] << (8 * k);
+            uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+            uint32_t s = tk_short_hash(lo, hi, len) & out.short_mask;
+            while (out.short_tab[s].len) s = (s + 1) & out.short_mask;
+            out.short_tab[s] = tk_short_entry{lo, hi, r, len};
+        } else if (len >= 9) {
+            uint32_t h1 = 0, h2 = 0;
+            for (uint32_t k = 0; k < len; ++k) {
+                h1 = h1 * TK_POLY_P1 + p[k];
+                h2 = h2 * TK_POLY_P2 + p[k];
+            }
+            uint32_t s = tk_long_hash(h1, len) & out.long_mask;
+            while (out.long_tab[s].len) s = (s + 1) & out.long_mask;
+            out.long_tab[s] = tk_long_entry{h2, r, len, offs[r]};
+        }
+    }
+
+    // PAIR: every split of every token whose halves are both tokens
+    std::vector<uint64_t> pairs;
+    pairs.reserve((size_t)n_ranks * 4);
+    std::string a, b;
+    for (uint32_t r = 256; r < n_ranks; ++r) {
+        const char* p = (const char*)blob + offs[r];
+        uint32_t len = offs[r + 1] - offs[r];
+        for (uint32_t k = 1; k < len; ++k) {
+            a.assign(p, k);
+            auto ia = by_bytes.find(a);
+            if (ia == by_bytes.end()) continue;
+            b.assign(p + k, len - k);
+            auto ib = by_bytes.find(b);
+            if (ib == by_bytes.end()) continue;
+            pairs.push_back(tk_pair_pack(ia->second, ib->second, r));
+        }
+    }
+    out.n_pairs = pairs.size();
+    uint32_t pcap = pow2_at_least(2 * pairs.size() + 1);
+    out.pair_mask = pcap - 1;
+    out.pair_tab.assign(pcap, TK_PAIR_EMPTY);
+    for (uint64_t e : pairs) {
+        uint64_t key = tk_pair_key(e);
+        uint32_t ida = (uint32_t)(key >> TK_ID_BITS), idb = (uint32_t)(key & ((1u << TK_ID_BITS) - 1u));
+        uint32_t s = tk_pair_hash(ida, idb) & out.pair_mask;
+        while (out.pair_tab[s] != TK_PAIR_EMPTY) s = (s + 1) & out.pair_mask;
+        out.pair_tab[s] = e;
+    }
+    return TK_OK;
+}

@@ -1,0 +1,53 @@
+// tk_tables.h -- host-side builder of the lookup tables the kernels read.
+//
+// Input is the validated rank table (rank i <-> token bytes i), i.e. the contents of the
+// FxHashMap built by reload_mergeable_ranks (reference src/tekkenizer.rs:776-816) and handed
+// to CoreBPE::new (:122-126).  Output is the flat, pointer-free image uploaded to HBM once
+// per context (tk_capi.cpp) -- and the same image is what the CPU wave emulator of the
+// test-suite runs the kernel source against.
+#ifndef TK_TABLES_H
+#define TK_TABLES_H
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "tk_hash.h"
+
+// Raw-pointer view consumed by the kernels (device pointers in the product).
+struct TkTablesView {
+    const uint16_t* uc_stage1;       // Unicode class trie, stage 1 (cp >> 7 -> block)
+    const uint32_t* uc_stage2;       // stage 2: 16 x 2-bit classes per word
+    const tk_short_entry* short_tab; // whole pieces of 2..8 bytes
+    const tk_long_entry* long_tab;   // whole pieces of >= 9 bytes
+    const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21
+    const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
+    const uint8_t* blob;             // token bytes, for verifying LONG hits
+    uint32_t short_mask, long_mask, pair_mask;
+    uint32_t n_ranks, num_special, bos_id, eos_id;
+    uint32_t p1inv, p2inv;           // inverses of the polynomial bases mod 2^32
+};
+
+struct TkHostTables {
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> offs;
+    std::vector<uint16_t> uc_stage1;
+    std::vector<uint32_t> uc_stage2;
+    std::vector<tk_short_entry> short_tab;
+    std::vector<tk_long_entry> long_tab;
+    std::vector<uint64_t> pair_tab;
+    std::vector<uint32_t> pair2;
+    uint32_t short_mask = 0, long_mask = 0, pair_mask = 0;
+    uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
+    uint32_t p1inv = 0, p2inv = 0;
+    uint64_t n_pairs = 0, n_short = 0, n_long = 0;
+
+    TkTablesView host_view() const;
+};
+
+// Returns 0 on success; on failure returns a negative TK_ERR_* code and fills `err`.
+int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
+                    uint32_t bos_id, uint32_t eos_id, TkHostTables& out, std::string& err);
+
+uint32_t tk_inverse_u32(uint32_t odd);
+
+#endif

@@ -1,0 +1,36 @@
+// tk_wave_hip.h -- the wave primitives of tk_encode_impl.h on gfx950 (wave64).
+#ifndef TK_WAVE_HIP_H
+#define TK_WAVE_HIP_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TK_DEV __device__ __forceinline__
+
+TK_DEV int wv_lane() { return (int)(threadIdx.x & 63u); }
+
+TK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
+
+// value of `v` in lane `src` (0..63); every lane of the wave must execute it
+TK_DEV uint32_t wv_shfl(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+
+// lane i receives lane i+1's value, lane 63 receives 0   (DPP wave_shl:1)
+TK_DEV uint32_t wv_up1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+}
+
+// lane i receives lane i-1's value, lane 0 receives 0     (DPP wave_shr:1)
+TK_DEV uint32_t wv_dn1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+// orders this wave's earlier global stores before its later loads (one wave only)
+TK_DEV void wv_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+
+#endif

@@ -1,0 +1,64 @@
+"""ctypes front-end of the CPU wave emulator (tests/emu/libtk_emu.so).  Test infrastructure."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libtk_emu.so"])
+        L = ctypes.CDLL(os.path.join(_HERE, "libtk_emu.so"))
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.emu_encode_batch.restype = ctypes.c_int
+        L.emu_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                       u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p,
+                                       u64p, u8p, u64p, u64p]
+        L.emu_last_error.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def pack_docs(docs):
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs], dtype=np.uint64)
+    data = np.frombuffer(b"".join(docs) or b"\0", dtype=np.uint8).copy()
+    return data, offs
+
+
+def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True, split_only=False):
+    """Runs the device algorithm on the emulator.  Returns (list of id lists, starts flags, n_deferred)."""
+    toffs = np.zeros(len(token_bytes) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
+    data, offs = pack_docs(docs)
+    n = int(offs[-1])
+    D = len(docs)
+    out = np.zeros(n + 2 * D + 1, np.uint32)
+    oo = np.zeros(D + 1, np.uint64)
+    dbg = np.zeros(max(n, 1), np.uint8)
+    ndef = ctypes.c_uint64(0)
+    nops = ctypes.c_uint64(0)
+    rc = lib().emu_encode_batch(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special,
+                                bos, eos, _p(data, ctypes.c_uint8), _p(offs, ctypes.c_uint64), D, int(add_bos),
+                                int(add_eos), int(split_only), _p(out, ctypes.c_uint32), _p(oo, ctypes.c_uint64),
+                                _p(dbg, ctypes.c_uint8), ctypes.byref(ndef), ctypes.byref(nops))
+    if rc != 0:
+        raise RuntimeError("emu_encode_batch rc=%d: %s" % (rc, lib().emu_last_error().decode()))
+    ids = [out[int(oo[d]):int(oo[d + 1])].tolist() for d in range(D)]
+    starts = []
+    for d in range(D):
+        a, b = int(offs[d]), int(offs[d + 1])
+        starts.append([i for i in range(b - a) if dbg[a + i]])
+    return ids, starts, int(ndef.value)

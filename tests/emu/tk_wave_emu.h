@@ -1,0 +1,158 @@
+// tk_wave_emu.h -- CPU emulation of one 64-lane wavefront with fibers (ucontext).
+//
+// TEST INFRASTRUCTURE ONLY.  It exists so that the CPU test-suite (no GPU in the build
+// container) can execute the very source of the device algorithm,
+// tekken-rs_amd/csrc/tk_encode_impl.h, lane by lane, and compare it with the oracle.  It is
+// never linked into libtekken_hip.so and is not reachable from the product API.
+//
+// Model: 64 fibers, one per lane.  A wave primitive (ballot / shuffle / ...) deposits the
+// lane's operand and yields to the scheduler; once every live lane has arrived the scheduler
+// publishes a snapshot and resumes the lanes.  The scheduler asserts that all lanes arrive at
+// the SAME primitive, which is exactly the discipline real hardware needs (wave operations
+// must be reached in wave-uniform control flow).
+#ifndef TK_WAVE_EMU_H
+#define TK_WAVE_EMU_H
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define TK_DEV static inline
+
+namespace tkemu {
+
+enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC };
+
+struct Wave {
+    ucontext_t sched;
+    ucontext_t ctx[64];
+    std::vector<char> stacks[64];
+    bool done[64];
+    int cur = 0;
+    int op[64];
+    uint32_t dep_u32[64];
+    uint8_t dep_pred[64];
+    uint32_t snap_u32[64];
+    uint64_t snap_ballot = 0;
+    std::function<void(int)> body;
+    uint64_t n_ops = 0;
+};
+
+extern Wave* g_wave;
+
+inline void yield_op(int op) {
+    Wave* w = g_wave;
+    w->op[w->cur] = op;
+    swapcontext(&w->ctx[w->cur], &w->sched);
+}
+
+inline void fiber_entry(int lane) {
+    Wave* w = g_wave;
+    w->body(lane);
+    w->done[lane] = true;
+    w->op[lane] = OP_NONE;
+    swapcontext(&w->ctx[lane], &w->sched);
+}
+
+inline void run_wave(const std::function<void(int)>& body) {
+    static Wave* wave = nullptr;
+    if (!wave) {
+        wave = new Wave();
+        for (int l = 0; l < 64; ++l) wave->stacks[l].resize(512 * 1024);
+    }
+    Wave* w = wave;
+    g_wave = w;
+    w->body = body;
+    for (int l = 0; l < 64; ++l) {
+        w->done[l] = false;
+        w->op[l] = OP_NONE;
+        getcontext(&w->ctx[l]);
+        w->ctx[l].uc_stack.ss_sp = w->stacks[l].data();
+        w->ctx[l].uc_stack.ss_size = w->stacks[l].size();
+        w->ctx[l].uc_link = nullptr;
+        makecontext(&w->ctx[l], (void (*)())fiber_entry, 1, l);
+    }
+    for (;;) {
+        int live = 0;
+        for (int l = 0; l < 64; ++l) {
+            if (w->done[l]) continue;
+            w->cur = l;
+            swapcontext(&w->sched, &w->ctx[l]);
+            if (!w->done[l]) ++live;
+        }
+        if (live == 0) break;
+        // every live lane is parked at a primitive: they must agree on which one
+        int op = OP_NONE;
+        for (int l = 0; l < 64; ++l) {
+            if (w->done[l]) continue;
+            if (op == OP_NONE) op = w->op[l];
+            else if (op != w->op[l]) {
+                fprintf(stderr, "tkemu: lanes diverged at a wave primitive (lane %d op %d vs %d)\n", l, w->op[l], op);
+                abort();
+            }
+        }
+        if (live != 64) {
+            // a lane left the kernel while others still execute wave primitives
+            fprintf(stderr, "tkemu: %d lanes exited early while others wait at op %d\n", 64 - live, op);
+            abort();
+        }
+        uint64_t b = 0;
+        for (int l = 0; l < 64; ++l) {
+            w->snap_u32[l] = w->dep_u32[l];
+            if (w->dep_pred[l]) b |= 1ull << l;
+        }
+        w->snap_ballot = b;
+        ++w->n_ops;
+    }
+}
+
+}  // namespace tkemu
+
+TK_DEV int wv_lane() { return tkemu::g_wave->cur; }
+
+TK_DEV uint64_t wv_ballot(bool p) {
+    tkemu::Wave* w = tkemu::g_wave;
+    w->dep_pred[w->cur] = p ? 1 : 0;
+    tkemu::yield_op(tkemu::OP_BALLOT);
+    return tkemu::g_wave->snap_ballot;
+}
+
+TK_DEV uint32_t wv_shfl(uint32_t v, int src) {
+    tkemu::Wave* w = tkemu::g_wave;
+    if (src < 0 || src > 63) {
+        fprintf(stderr, "tkemu: wv_shfl source lane %d out of range (lane %d)\n", src, w->cur);
+        abort();
+    }
+    w->dep_u32[w->cur] = v;
+    tkemu::yield_op(tkemu::OP_SHFL);
+    return tkemu::g_wave->snap_u32[src];
+}
+
+TK_DEV uint32_t wv_up1(uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    int lane = w->cur;
+    w->dep_u32[lane] = v;
+    tkemu::yield_op(tkemu::OP_UP1);
+    return lane < 63 ? tkemu::g_wave->snap_u32[lane + 1] : 0u;
+}
+
+TK_DEV uint32_t wv_dn1(uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    int lane = w->cur;
+    w->dep_u32[lane] = v;
+    tkemu::yield_op(tkemu::OP_DN1);
+    return lane > 0 ? tkemu::g_wave->snap_u32[lane - 1] : 0u;
+}
+
+TK_DEV void wv_sync() { tkemu::yield_op(tkemu::OP_SYNC); }
+
+TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) {
+    uint32_t old = *p;
+    *p = old + v;
+    return old;
+}
+
+#endif

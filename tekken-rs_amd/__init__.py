@@ -1,0 +1,405 @@
+"""tekken-rs_amd -- MI355X-native batch tokenization behind tekken-rs's `Tekkenizer::encode`.
+
+Python is plumbing here: this module only loads the in-tree C-ABI library
+(`libtekken_hip.so`, built from csrc/ by `make -C tekken-rs_amd`) with ctypes and mirrors the
+reference's public surface for this path --
+
+    Tekkenizer.from_file / encode / decode / SpecialTokenPolicy     (reference src/tekkenizer.rs:222,378,436;
+                                                                     src/special_tokens.rs:128-136)
+
+plus the batch and device-resident entry points that the GPU path adds.  There is no CPU
+fallback: if the library or a HIP device is missing, calls raise.
+
+The directory name contains a hyphen, so import it with
+`importlib.import_module("tekken-rs_amd")`.
+"""
+import ctypes
+import enum
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtekken_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+TK_OK = 0
+TK_ERR_INVALID_CONFIG = -1
+TK_ERR_RUNTIME = -2
+TK_ERR_INVALID_UTF8 = -3
+TK_ERR_NO_DEVICE = -4
+TK_ERR_INVALID_ARG = -5
+TK_ERR_IO = -6
+TK_ERR_JSON = -7
+TK_ERR_BASE64 = -8
+TK_ERR_TOKEN_NOT_FOUND = -9
+TK_ERR_SPECIAL_POLICY = -10
+
+
+class TokenizerError(Exception):
+    """Mirror of tekken::errors::TokenizerError (reference src/errors.rs:23-59)."""
+    KIND = {TK_ERR_INVALID_CONFIG: "InvalidConfig", TK_ERR_RUNTIME: "Tokenizers", TK_ERR_INVALID_UTF8: "Tokenizers",
+            TK_ERR_NO_DEVICE: "Tokenizers", TK_ERR_INVALID_ARG: "InvalidConfig", TK_ERR_IO: "Io", TK_ERR_JSON: "Json",
+            TK_ERR_BASE64: "Base64", TK_ERR_TOKEN_NOT_FOUND: "TokenNotFound",
+            TK_ERR_SPECIAL_POLICY: "SpecialTokenPolicy"}
+
+    def __init__(self, code, message):
+        self.code = code
+        self.kind = self.KIND.get(code, "Tokenizers")
+        super().__init__("%s: %s" % (self.kind, message))
+
+
+class SpecialTokenPolicy(enum.IntEnum):
+    """reference src/special_tokens.rs:128-136"""
+    Ignore = 0
+    Keep = 1
+    Raise = 2
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [("ids", ctypes.POINTER(ctypes.c_uint32)), ("offsets", ctypes.POINTER(ctypes.c_uint64)),
+                ("n_ids", ctypes.c_uint64), ("n_docs", ctypes.c_uint64)]
+
+
+_LIB = None
+
+
+def build(force=False):
+    """Compile libtekken_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "libtekken_hip.so"])
+    return LIB_PATH
+
+
+def lib():
+    """The C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libtekken_hip.so is missing: run `make -C tekken-rs_amd` (or __graft_entry__.build())")
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
+    # If torch is going to live in this process it must be loaded FIRST so that our DT_NEEDED
+    # libamdhip64.so.7 resolves to the copy torch already mapped (two runtimes cannot both open the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)
+    L.tk_ctx_create.restype = ctypes.c_int
+    L.tk_ctx_create.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                ctypes.c_int, ctypes.POINTER(vp)]
+    L.tk_ctx_destroy.argtypes = [vp]
+    L.tk_last_error.restype = ctypes.c_char_p
+    L.tk_last_error.argtypes = [vp]
+    L.tk_encode_batch.restype = ctypes.c_int
+    L.tk_encode_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(_Result)]
+    L.tk_free_result.argtypes = [ctypes.POINTER(_Result)]
+    L.tk_encode_batch_device.restype = ctypes.c_int
+    L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
+                                         ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    L.tk_last_timing.restype = ctypes.c_int
+    L.tk_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.tk_last_stats.restype = ctypes.c_int
+    L.tk_last_stats.argtypes = [vp, u64p, u64p]
+    L.tk_split_batch.restype = ctypes.c_int
+    L.tk_split_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, u8p]
+    L.tk_tokenizer_from_file.restype = ctypes.c_int
+    L.tk_tokenizer_from_file.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(vp)]
+    L.tk_tokenizer_from_json.restype = ctypes.c_int
+    L.tk_tokenizer_from_json.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+    L.tk_tokenizer_destroy.argtypes = [vp]
+    L.tk_tokenizer_last_error.restype = ctypes.c_char_p
+    L.tk_tokenizer_last_error.argtypes = [vp]
+    L.tk_tokenizer_encode.restype = ctypes.c_int
+    L.tk_tokenizer_encode.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(u32p), ctypes.POINTER(ctypes.c_size_t)]
+    L.tk_tokenizer_encode_batch.restype = ctypes.c_int
+    L.tk_tokenizer_encode_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(_Result)]
+    L.tk_free_ids.argtypes = [u32p]
+    L.tk_tokenizer_decode.restype = ctypes.c_int
+    L.tk_tokenizer_decode.argtypes = [vp, u32p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_size_t)]
+    L.tk_free_text.argtypes = [ctypes.c_void_p]
+    L.tk_tokenizer_vocab_size.restype = ctypes.c_uint32
+    L.tk_tokenizer_vocab_size.argtypes = [vp]
+    L.tk_tokenizer_num_special_tokens.restype = ctypes.c_uint32
+    L.tk_tokenizer_num_special_tokens.argtypes = [vp]
+    L.tk_tokenizer_version.restype = ctypes.c_char_p
+    L.tk_tokenizer_version.argtypes = [vp]
+    L.tk_tokenizer_control_token.restype = ctypes.c_int
+    L.tk_tokenizer_control_token.argtypes = [vp, ctypes.c_char_p, u32p]
+    L.tk_tokenizer_is_special.restype = ctypes.c_int
+    L.tk_tokenizer_is_special.argtypes = [vp, ctypes.c_uint32]
+    L.tk_tokenizer_is_byte.restype = ctypes.c_int
+    L.tk_tokenizer_is_byte.argtypes = [vp, ctypes.c_uint32]
+    L.tk_tokenizer_id_to_piece.restype = ctypes.c_int
+    L.tk_tokenizer_id_to_piece.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.POINTER(ctypes.c_size_t)]
+    L.tk_tokenizer_id_to_byte_piece.restype = ctypes.c_int
+    L.tk_tokenizer_id_to_byte_piece.argtypes = [vp, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                                ctypes.POINTER(ctypes.c_size_t)]
+    L.tk_tokenizer_ctx.restype = vp
+    L.tk_tokenizer_ctx.argtypes = [vp]
+    L.tk_tokenizer_rank_table.restype = ctypes.c_int
+    L.tk_tokenizer_rank_table.argtypes = [vp, ctypes.POINTER(u8p), ctypes.POINTER(u32p), u32p]
+    _LIB = L
+    return L
+
+
+def _p(arr, ct):
+    return arr.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def pack_docs(docs):
+    """list[bytes] -> (uint8[n_bytes], uint64[D+1]) packed byte buffer + doc-offset array."""
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    if docs:
+        offs[1:] = np.cumsum([len(d) for d in docs], dtype=np.uint64)
+    joined = b"".join(docs)
+    data = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(0, np.uint8)
+    return data, offs
+
+
+def _take_result(res):
+    n, D = int(res.n_ids), int(res.n_docs)
+    ids = np.ctypeslib.as_array(res.ids, shape=(max(n, 1),))[:n].copy()
+    offs = np.ctypeslib.as_array(res.offsets, shape=(D + 1,)).copy()
+    lib().tk_free_result(ctypes.byref(res))
+    return ids, offs
+
+
+class Engine:
+    """Engine-level context: the replacement for CoreBPE (reference src/tekkenizer.rs:125, 384-386)."""
+
+    def __init__(self, token_bytes, num_special, bos_id, eos_id, device=0, _borrowed=None):
+        self._own = _borrowed is None
+        if _borrowed is not None:
+            self._h = _borrowed
+            return
+        toks = list(token_bytes)
+        offs = np.zeros(len(toks) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(t) for t in toks], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(toks) or b"\0", dtype=np.uint8).copy()
+        h = ctypes.c_void_p()
+        rc = lib().tk_ctx_create(_p(blob, ctypes.c_uint8), _p(offs, ctypes.c_uint32), len(toks), num_special, bos_id,
+                                 eos_id, device, ctypes.byref(h))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and self._own:
+            lib().tk_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        return TokenizerError(rc, lib().tk_last_error(self._h).decode())
+
+    def encode_batch(self, data, offs, add_bos=True, add_eos=True, validate_utf8=False):
+        """Host buffers in, host buffers out: (ids uint32[T], out_offsets uint64[D+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        res = _Result()
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        rc = lib().tk_encode_batch(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1,
+                                   int(add_bos), int(add_eos), int(validate_utf8), ctypes.byref(res))
+        if rc != TK_OK:
+            raise self._err(rc)
+        return _take_result(res)
+
+    def encode_docs(self, docs, add_bos=True, add_eos=True, validate_utf8=False):
+        data, offs = pack_docs(docs)
+        ids, oo = self.encode_batch(data, offs, add_bos, add_eos, validate_utf8)
+        return [ids[int(oo[d]):int(oo[d + 1])].tolist() for d in range(len(docs))]
+
+    def encode_batch_device(self, d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos=True, add_eos=True, stream=0):
+        """Inputs resident in HBM (raw device pointers).  Returns (d_ids_ptr, d_out_offs_ptr, n_ids);
+        the output buffers belong to the context and stay valid until the next call."""
+        d_ids, d_oo, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0)
+        rc = lib().tk_encode_batch_device(self._h, ctypes.c_void_p(d_bytes_ptr), ctypes.c_void_p(d_offs_ptr), n_docs,
+                                          n_bytes, int(add_bos), int(add_eos), ctypes.c_void_p(stream),
+                                          ctypes.byref(d_ids), ctypes.byref(d_oo), ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        return d_ids.value, d_oo.value, int(n.value)
+
+    def last_timing(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        lib().tk_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
+        return {"pipeline_ms": a.value, "encode_kernel_ms": b.value}
+
+    def last_stats(self):
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        lib().tk_last_stats(self._h, ctypes.byref(a), ctypes.byref(b))
+        return {"long_docs": int(a.value)}
+
+    def split_docs(self, docs):
+        """Piece-start offsets per document (vocab-free split, debug / parity entry)."""
+        data, offs = pack_docs(docs)
+        n = int(offs[-1])
+        out = np.zeros(max(n, 1), np.uint8)
+        dbuf = data if n else np.zeros(1, np.uint8)
+        rc = lib().tk_split_batch(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(docs),
+                                  _p(out, ctypes.c_uint8))
+        if rc != TK_OK:
+            raise self._err(rc)
+        res = []
+        for d in range(len(docs)):
+            a, b = int(offs[d]), int(offs[d + 1])
+            res.append(np.nonzero(out[a:b])[0].tolist())
+        return res
+
+
+class Tekkenizer:
+    """Mirror of tekken::tekkenizer::Tekkenizer for the text path (reference src/tekkenizer.rs)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path, device=0):
+        """Tekkenizer::from_file (src/tekkenizer.rs:222-248).  device=-1: host-only (no encode)."""
+        h = ctypes.c_void_p()
+        rc = lib().tk_tokenizer_from_file(os.fsencode(path), device, ctypes.byref(h))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_tokenizer_last_error(None).decode())
+        return cls(h)
+
+    @classmethod
+    def from_json(cls, text, device=0):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        h = ctypes.c_void_p()
+        rc = lib().tk_tokenizer_from_json(raw, len(raw), device, ctypes.byref(h))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_tokenizer_last_error(None).decode())
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tk_tokenizer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        return TokenizerError(rc, lib().tk_tokenizer_last_error(self._h).decode())
+
+    def encode(self, text, add_bos=False, add_eos=False):
+        """Tekkenizer::encode (src/tekkenizer.rs:378-405)."""
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        ids = ctypes.POINTER(ctypes.c_uint32)()
+        n = ctypes.c_size_t(0)
+        rc = lib().tk_tokenizer_encode(self._h, raw, len(raw), int(add_bos), int(add_eos), ctypes.byref(ids),
+                                       ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        out = [ids[i] for i in range(n.value)]
+        lib().tk_free_ids(ids)
+        return out
+
+    def encode_batch(self, docs, add_bos=False, add_eos=False):
+        data, offs = pack_docs([d.encode("utf-8") if isinstance(d, str) else bytes(d) for d in docs])
+        res = _Result()
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        rc = lib().tk_tokenizer_encode_batch(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(docs),
+                                             int(add_bos), int(add_eos), ctypes.byref(res))
+        if rc != TK_OK:
+            raise self._err(rc)
+        ids, oo = _take_result(res)
+        return [ids[int(oo[d]):int(oo[d + 1])].tolist() for d in range(len(docs))]
+
+    def decode(self, ids, policy=SpecialTokenPolicy.Ignore):
+        """Tekkenizer::decode (src/tekkenizer.rs:436-443)."""
+        arr = np.ascontiguousarray(ids, dtype=np.uint32)
+        buf = arr if len(arr) else np.zeros(1, np.uint32)
+        text = ctypes.c_void_p()
+        n = ctypes.c_size_t(0)
+        rc = lib().tk_tokenizer_decode(self._h, _p(buf, ctypes.c_uint32), len(arr), int(policy), ctypes.byref(text),
+                                       ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        out = ctypes.string_at(text, n.value).decode("utf-8")
+        lib().tk_free_text(text)
+        return out
+
+    def _piece(self, fn, *args):
+        text = ctypes.c_void_p()
+        n = ctypes.c_size_t(0)
+        rc = fn(self._h, *args, ctypes.byref(text), ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        out = ctypes.string_at(text, n.value)
+        lib().tk_free_text(text)
+        return out
+
+    def id_to_piece(self, token_id):
+        return self._piece(lib().tk_tokenizer_id_to_piece, token_id).decode("utf-8")
+
+    def id_to_byte_piece(self, token_id, policy=SpecialTokenPolicy.Raise):
+        return self._piece(lib().tk_tokenizer_id_to_byte_piece, token_id, int(policy))
+
+    def vocab_size(self):
+        return lib().tk_tokenizer_vocab_size(self._h)
+
+    def num_special_tokens(self):
+        return lib().tk_tokenizer_num_special_tokens(self._h)
+
+    def version(self):
+        return lib().tk_tokenizer_version(self._h).decode()
+
+    def get_control_token(self, name):
+        v = ctypes.c_uint32(0)
+        rc = lib().tk_tokenizer_control_token(self._h, name.encode("utf-8"), ctypes.byref(v))
+        if rc != TK_OK:
+            raise self._err(rc)
+        return v.value
+
+    def bos_id(self):
+        return self.get_control_token("<s>")
+
+    def eos_id(self):
+        return self.get_control_token("</s>")
+
+    def pad_id(self):
+        return self.get_control_token("<pad>")
+
+    def unk_id(self):
+        return self.get_control_token("<unk>")
+
+    def is_special_token(self, token_id):
+        return bool(lib().tk_tokenizer_is_special(self._h, token_id))
+
+    def is_byte(self, token_id):
+        return bool(lib().tk_tokenizer_is_byte(self._h, token_id))
+
+    def engine(self):
+        """The engine context behind this tokenizer (None for host-only objects)."""
+        h = lib().tk_tokenizer_ctx(self._h)
+        return Engine(None, 0, 0, 0, _borrowed=ctypes.c_void_p(h)) if h else None
+
+    def rank_table(self):
+        """list[bytes]: token bytes by rank (what reload_mergeable_ranks produced)."""
+        blob = ctypes.POINTER(ctypes.c_uint8)()
+        offs = ctypes.POINTER(ctypes.c_uint32)()
+        n = ctypes.c_uint32(0)
+        lib().tk_tokenizer_rank_table(self._h, ctypes.byref(blob), ctypes.byref(offs), ctypes.byref(n))
+        o = np.ctypeslib.as_array(offs, shape=(n.value + 1,))
+        total = int(o[-1])
+        b = ctypes.string_at(blob, total)
+        return [b[int(o[i]):int(o[i + 1])] for i in range(n.value)]

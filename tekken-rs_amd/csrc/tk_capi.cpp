@@ -1,0 +1,397 @@
+// tk_capi.cpp -- engine-level C ABI (include/tekken_hip.h): context, device tables, the
+// batch pipeline  encode(pass 1) -> scan -> compact [-> pass 2 -> scan -> compact].
+//
+// Replaces CoreBPE::new / CoreBPE::encode at reference src/tekkenizer.rs:125 and :384-386 and
+// fuses the id shift / BOS / EOS of :390-402.  There is NO CPU fallback in this file: without
+// a HIP device every entry point fails with TK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tekken_hip.h"
+#include "tk_engine.h"
+#include "tk_kernels.h"
+#include "tk_tables.h"
+
+static thread_local std::string g_tls_err;
+
+void tk_set_tls_error(const std::string& e) { g_tls_err = e; }
+const std::string& tk_get_tls_error() { return g_tls_err; }
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+}  // namespace
+
+struct tk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    TkHostTables host;
+    TkTablesView dview;
+    DevBuf t_uc1, t_uc2, t_short, t_long, t_pair, t_pair2, t_blob;
+    DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float pipeline_ms = 0.f, encode_ms = 0.f;
+    uint64_t n_long_docs = 0;
+    uint32_t* dbg_mark = nullptr;  // pinned host memory, only with TK_DEBUG_MARKS
+};
+
+#define TK_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                        \
+            return TK_ERR_RUNTIME;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+static int upload(tk_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    TK_HIP(c, b.reserve(bytes ? bytes : 16));
+    if (bytes) TK_HIP(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return TK_OK;
+}
+
+extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_offsets, uint32_t n_ranks,
+                             uint32_t num_special_tokens, uint32_t bos_id, uint32_t eos_id, int device_id,
+                             tk_ctx** out_ctx) {
+    if (!out_ctx) { g_tls_err = "out_ctx is NULL"; return TK_ERR_INVALID_ARG; }
+    *out_ctx = nullptr;
+    tk_ctx* c = new tk_ctx();
+    std::string err;
+    int rc = tk_build_tables(token_bytes, token_offsets, n_ranks, num_special_tokens, bos_id, eos_id, c->host, err);
+    if (rc != TK_OK) { g_tls_err = err; delete c; return rc; }
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_tls_err = "no HIP device available (the tokenization path has no CPU fallback)";
+        delete c;
+        return TK_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) {
+        g_tls_err = "device_id out of range";
+        delete c;
+        return TK_ERR_INVALID_ARG;
+    }
+    c->device = device_id;
+    auto fail = [&](int code) {
+        g_tls_err = c->err;
+        tk_ctx_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device_id) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TK_ERR_RUNTIME); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "hipStreamCreate failed";
+        return fail(TK_ERR_RUNTIME);
+    }
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
+
+    const TkHostTables& h = c->host;
+    if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
+        (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||
+        (rc = upload(c, c->t_short, h.short_tab.data(), h.short_tab.size() * sizeof(tk_short_entry))) ||
+        (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
+        (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
+        (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
+        (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())))
+        return fail(rc);
+    c->dview = h.host_view();
+    c->dview.uc_stage1 = (const uint16_t*)c->t_uc1.p;
+    c->dview.uc_stage2 = (const uint32_t*)c->t_uc2.p;
+    c->dview.short_tab = (const tk_short_entry*)c->t_short.p;
+    c->dview.long_tab = (const tk_long_entry*)c->t_long.p;
+    c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
+    c->dview.pair2 = (const uint32_t*)c->t_pair2.p;
+    c->dview.blob = (const uint8_t*)c->t_blob.p;
+
+    if (c->counters.reserve(64) != hipSuccess) { c->err = "hipMalloc(counters) failed"; return fail(TK_ERR_RUNTIME); }
+    // the wave primitives (DPP wave shifts, bpermute) are checked once on the real device
+    uint32_t bad = 1;
+    if (hipMemsetAsync(c->counters.p, 0, 64, c->stream) != hipSuccess ||
+        tk_launch_wave_selftest((uint32_t*)c->counters.p, c->stream) != hipSuccess ||
+        hipMemcpyAsync(&bad, c->counters.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        c->err = std::string("wave self-test launch failed: ") + hipGetErrorString(hipGetLastError());
+        return fail(TK_ERR_RUNTIME);
+    }
+    if (bad != 0) {
+        c->err = "wave primitive self-test failed on this device (mask " + std::to_string(bad) + ")";
+        return fail(TK_ERR_RUNTIME);
+    }
+    *out_ctx = c;
+    return TK_OK;
+}
+
+extern "C" void tk_ctx_destroy(tk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_short, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob,
+                      &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
+                      &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg};
+    for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* tk_last_error(const tk_ctx* c) { return c ? c->err.c_str() : g_tls_err.c_str(); }
+
+const TkHostTables* tk_ctx_host_tables(const tk_ctx* c) { return c ? &c->host : nullptr; }
+
+// counters layout (u32): [0] work queue head, [1] deferred documents, [2] invalid docs, [3] max deferred length
+static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
+                        int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
+    const uint64_t cap = n_bytes + 2 * n_docs + 64;
+    TK_HIP(c, c->staging.reserve(cap * 4));
+    TK_HIP(c, c->out_ids.reserve(cap * 4));
+    TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
+    TK_HIP(c, c->block_sums.reserve((n_docs / 2048 + 4) * 8));
+    TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
+
+    TkEncodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bytes = d_bytes;
+    a.doc_offs = d_offs;
+    a.n_docs = n_docs;
+    a.staging = (uint32_t*)c->staging.p;
+    a.counts = (uint32_t*)c->counts.p;
+    a.work_counter = (uint32_t*)c->counters.p;
+    a.defer_count = (uint32_t*)c->counters.p + 1;
+    a.defer_list = (uint32_t*)c->defer_list.p;
+    a.add_bos = add_bos;
+    a.add_eos = add_eos;
+    a.t = c->dview;
+    if (getenv("TK_DEBUG_MARKS")) {
+        if (!c->dbg_mark) {
+            TK_HIP(c, hipHostMalloc((void**)&c->dbg_mark, 256, hipHostMallocMapped));
+            memset(c->dbg_mark, 0, 256);
+        }
+        a.dbg_mark = c->dbg_mark;
+    }
+
+    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, s));
+    TK_HIP(c, hipEventRecord(c->ev[0], s));
+    uint64_t want = (n_docs + 7) / 8;
+    uint32_t n_waves = (uint32_t)(want < 8192 ? (want ? want : 1) : 8192);
+    TK_HIP(c, tk_launch_encode(a, 0, n_waves, s));
+    TK_HIP(c, hipEventRecord(c->ev[1], s));
+    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs,
+                                (uint32_t*)c->out_ids.p, s));
+    TK_HIP(c, hipEventRecord(c->ev[2], s));
+    uint32_t ctr[4] = {0, 0, 0, 0};
+    uint64_t total = 0;
+    TK_HIP(c, hipMemcpyAsync(ctr, c->counters.p, 16, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    c->n_long_docs = ctr[1];
+    const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
+    if (dbg) fprintf(stderr, "[tk] pass1 done: docs=%llu deferred=%u total=%llu\n", (unsigned long long)n_docs, ctr[1], (unsigned long long)total);
+    if (ctr[1] != 0 && getenv("TK_DEBUG_SKIP_PASS2") == nullptr) {
+        // rare: documents with a long piece that missed the vocabulary need the scratch-backed
+        // cooperative merge.  Size the scratch from the longest deferred document.
+        const uint32_t n_def = ctr[1];
+        uint32_t maxlen32 = 0;
+        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 3, 0, 4, s));
+        TK_HIP(c, tk_launch_defer_maxlen((const uint32_t*)c->defer_list.p, n_def, d_offs, (uint32_t*)c->counters.p + 3, s));
+        TK_HIP(c, hipMemcpyAsync(&maxlen32, (uint32_t*)c->counters.p + 3, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        const uint64_t maxlen = maxlen32;
+        if (dbg) fprintf(stderr, "[tk] pass2: n_def=%u maxlen=%llu\n", n_def, (unsigned long long)maxlen);
+        const uint64_t words = 4 * maxlen + 2 * ((maxlen + 63) / 64) + 64;
+        // the grid is launched in blocks of 4 waves and EVERY launched wave owns a scratch slice
+        uint64_t waves2 = n_def < 1024 ? n_def : 1024;
+        const uint64_t budget_words = (8ull << 30) / 4;
+        if (waves2 * words > budget_words) waves2 = budget_words / words;
+        waves2 = ((waves2 + 3) / 4) * 4;
+        if (waves2 == 0) waves2 = 4;
+        TK_HIP(c, c->scratch.reserve(waves2 * words * 4));
+        a.todo_list = (const uint32_t*)c->defer_list.p;
+        a.n_todo = n_def;
+        a.scratch = (uint32_t*)c->scratch.p;
+        a.scratch_words_per_wave = words;
+        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
+        TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
+        if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] pass2 kernel done\n"); }
+        TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
+        TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs,
+                                    (uint32_t*)c->out_ids.p, s));
+        TK_HIP(c, hipEventRecord(c->ev[2], s));
+        TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+    }
+    (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[0], c->ev[2]);
+    *n_ids = total;
+    return TK_OK;
+}
+
+extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
+                                      uint64_t n_bytes, int add_bos, int add_eos, void* hip_stream, void** d_ids,
+                                      void** d_out_offsets, uint64_t* n_ids) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!d_doc_offsets || (!d_bytes && n_bytes) || !d_ids || !d_out_offsets || !n_ids) {
+        c->err = "null argument";
+        return TK_ERR_INVALID_ARG;
+    }
+    if (n_docs >= 0xFFFFFFF0ull) { c->err = "too many documents in one batch"; return TK_ERR_INVALID_ARG; }
+    TK_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    int rc = run_pipeline(c, (const uint8_t*)d_bytes, (const uint64_t*)d_doc_offsets, n_docs, n_bytes, add_bos,
+                          add_eos, s, n_ids);
+    if (rc != TK_OK) return rc;
+    *d_ids = c->out_ids.p;
+    *d_out_offsets = c->out_offs.p;
+    return TK_OK;
+}
+
+static int check_offsets(tk_ctx* c, const uint64_t* doc_offsets, uint64_t n_docs) {
+    if (doc_offsets[0] != 0) { c->err = "doc_offsets[0] must be 0"; return TK_ERR_INVALID_ARG; }
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_offsets[d + 1] < doc_offsets[d]) { c->err = "doc_offsets must be non-decreasing"; return TK_ERR_INVALID_ARG; }
+    return TK_OK;
+}
+
+static int stage_input(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs) {
+    const uint64_t n_bytes = doc_offsets[n_docs];
+    TK_HIP(c, c->in_bytes.reserve(n_bytes + 64));
+    TK_HIP(c, c->in_offs.reserve((n_docs + 1) * 8));
+    if (n_bytes) TK_HIP(c, hipMemcpyAsync(c->in_bytes.p, bytes, n_bytes, hipMemcpyHostToDevice, c->stream));
+    TK_HIP(c, hipMemcpyAsync(c->in_offs.p, doc_offsets, (n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    return TK_OK;
+}
+
+extern "C" int tk_encode_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                               int add_bos, int add_eos, int validate_utf8, tk_result* out) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!doc_offsets || !out || (!bytes && doc_offsets[n_docs])) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    if (n_docs >= 0xFFFFFFF0ull) { c->err = "too many documents in one batch"; return TK_ERR_INVALID_ARG; }
+    memset(out, 0, sizeof(*out));
+    int rc = check_offsets(c, doc_offsets, n_docs);
+    if (rc != TK_OK) return rc;
+    TK_HIP(c, hipSetDevice(c->device));
+    const uint64_t n_bytes = doc_offsets[n_docs];
+    if ((rc = stage_input(c, bytes, doc_offsets, n_docs)) != TK_OK) return rc;
+    if (validate_utf8) {
+        uint32_t bad = 0;
+        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 2, 0, 4, c->stream));
+        TK_HIP(c, tk_launch_validate((const uint8_t*)c->in_bytes.p, (const uint64_t*)c->in_offs.p, n_docs,
+                                     (uint32_t*)c->counters.p + 2, c->stream));
+        TK_HIP(c, hipMemcpyAsync(&bad, (uint32_t*)c->counters.p + 2, 4, hipMemcpyDeviceToHost, c->stream));
+        TK_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad) {
+            c->err = std::to_string(bad) + " document(s) are not valid UTF-8";
+            return TK_ERR_INVALID_UTF8;
+        }
+    }
+    uint64_t n_ids = 0;
+    rc = run_pipeline(c, (const uint8_t*)c->in_bytes.p, (const uint64_t*)c->in_offs.p, n_docs, n_bytes, add_bos,
+                      add_eos, c->stream, &n_ids);
+    if (rc != TK_OK) return rc;
+    uint32_t* h_ids = nullptr;
+    uint64_t* h_offs = nullptr;
+    TK_HIP(c, hipHostMalloc((void**)&h_ids, (n_ids ? n_ids : 1) * 4, hipHostMallocDefault));
+    hipError_t e = hipHostMalloc((void**)&h_offs, (n_docs + 1) * 8, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipHostFree(h_ids); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    if (n_ids) e = hipMemcpyAsync(h_ids, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_offs, c->out_offs.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h_ids); (void)hipHostFree(h_offs);
+        c->err = std::string("result copy failed: ") + hipGetErrorString(e);
+        return TK_ERR_RUNTIME;
+    }
+    out->ids = h_ids;
+    out->offsets = h_offs;
+    out->n_ids = n_ids;
+    out->n_docs = n_docs;
+    return TK_OK;
+}
+
+extern "C" void tk_free_result(tk_result* r) {
+    if (!r) return;
+    if (r->ids) (void)hipHostFree(r->ids);
+    if (r->offsets) (void)hipHostFree(r->offsets);
+    memset(r, 0, sizeof(*r));
+}
+
+extern "C" const uint32_t* tk_debug_marks(const tk_ctx* c) { return c ? c->dbg_mark : nullptr; }
+
+extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode_kernel_ms) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    if (pipeline_ms) *pipeline_ms = c->pipeline_ms;
+    if (encode_kernel_ms) *encode_kernel_ms = c->encode_ms;
+    return TK_OK;
+}
+
+extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    if (n_long_docs) *n_long_docs = c->n_long_docs;
+    if (reserved) *reserved = 0;
+    return TK_OK;
+}
+
+extern "C" int tk_split_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                              uint8_t* out_is_start) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!doc_offsets || (!bytes && doc_offsets[n_docs]) || !out_is_start) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    int rc = check_offsets(c, doc_offsets, n_docs);
+    if (rc != TK_OK) return rc;
+    TK_HIP(c, hipSetDevice(c->device));
+    const uint64_t n_bytes = doc_offsets[n_docs];
+    if ((rc = stage_input(c, bytes, doc_offsets, n_docs)) != TK_OK) return rc;
+    TK_HIP(c, c->dbg.reserve(n_bytes + 64));
+    TK_HIP(c, c->staging.reserve((n_bytes + 2 * n_docs + 64) * 4));
+    TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
+    TkEncodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bytes = (const uint8_t*)c->in_bytes.p;
+    a.doc_offs = (const uint64_t*)c->in_offs.p;
+    a.n_docs = n_docs;
+    a.staging = (uint32_t*)c->staging.p;
+    a.counts = (uint32_t*)c->counts.p;
+    a.work_counter = (uint32_t*)c->counters.p;
+    a.defer_count = (uint32_t*)c->counters.p + 1;
+    a.defer_list = (uint32_t*)c->defer_list.p;
+    a.dbg_starts = (uint8_t*)c->dbg.p;
+    a.split_only = 1;
+    a.t = c->dview;
+    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    TK_HIP(c, hipMemsetAsync(c->dbg.p, 0, n_bytes + 64, c->stream));
+    uint64_t want = (n_docs + 7) / 8;
+    TK_HIP(c, tk_launch_encode(a, 2, (uint32_t)(want < 8192 ? (want ? want : 1) : 8192), c->stream));
+    if (n_bytes) TK_HIP(c, hipMemcpyAsync(out_is_start, c->dbg.p, n_bytes, hipMemcpyDeviceToHost, c->stream));
+    TK_HIP(c, hipStreamSynchronize(c->stream));
+    return TK_OK;
+}

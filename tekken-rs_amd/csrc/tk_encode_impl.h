@@ -19,12 +19,12 @@
 //      tiktoken's _byte_pair_merge); pair ranks come from PAIR2/PAIR
 //   6. surviving part heads are compacted with popcounts and written as final ids
 //
-// Pieces that do not fit a window (>~60 bytes) take tk_long_piece(): sequential end search,
-// wave-wide polynomial hash, LONG probe, and -- only in the second pass, which owns scratch
-// memory -- a wave-cooperative merge with block minima.
+// A document with a piece that does not fit a window (>~60 bytes) is handed to a second pass
+// (tk_encode_doc_seq): sequential end search per piece, wave-wide polynomial hash, LONG probe
+// and, on a miss, a wave-cooperative merge over scratch memory with per-64-part block minima.
 //
 // The file is included with a set of wave primitives already defined (wv_lane, wv_ballot,
-// wv_shfl, wv_up1, wv_dn1, wv_sync, wv_atomic_add, TK_DEV): tk_wave_hip.h for gfx950, and a
+// wv_shfl, wv_first, wv_first64, wv_up1, wv_dn1, wv_sync, wv_atomic_add, wv_atomic_add_all, TK_DEV): tk_wave_hip.h for gfx950, and a
 // fiber emulator in tests/emu/ that lets the CPU test-suite run this very source.
 #ifndef TK_ENCODE_IMPL_H
 #define TK_ENCODE_IMPL_H
@@ -70,19 +70,20 @@ TK_DEV uint32_t tk_uc_class(const TkTablesView& t, uint32_t cp) {
 
 TK_DEV uint32_t tk_probe_short(const TkTablesView& t, uint32_t lo, uint32_t hi, uint32_t len) {
     uint32_t s = tk_short_hash(lo, hi, len) & t.short_mask;
-    for (;;) {
+    for (uint32_t tries = 0; tries <= t.short_mask; ++tries) {  // load factor <= 1/2: an empty slot is always met
         tk_short_entry e = t.short_tab[s];
         if (e.len == 0u) return TK_RANK_MAX;
         if (e.len == len && e.key_lo == lo && e.key_hi == hi) return e.rank;
         s = (s + 1u) & t.short_mask;
     }
+    return TK_RANK_MAX;
 }
 
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so
 // that the result is exact, not probabilistic.
 TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, uint32_t len, const uint8_t* text) {
     uint32_t s = tk_long_hash(h1, len) & t.long_mask;
-    for (;;) {
+    for (uint32_t tries = 0; tries <= t.long_mask; ++tries) {
         tk_long_entry e = t.long_tab[s];
         if (e.len == 0u) return TK_RANK_MAX;
         if (e.len == len && e.tag == h2) {
@@ -93,17 +94,19 @@ TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, u
         }
         s = (s + 1u) & t.long_mask;
     }
+    return TK_RANK_MAX;
 }
 
 TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
     uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
     uint32_t s = tk_pair_hash(a, b) & t.pair_mask;
-    for (;;) {
+    for (uint32_t tries = 0; tries <= t.pair_mask; ++tries) {
         uint64_t e = t.pair_tab[s];
         if (e == TK_PAIR_EMPTY) return TK_RANK_MAX;
         if (tk_pair_key(e) == key) return tk_pair_rank(e);
         s = (s + 1u) & t.pair_mask;
     }
+    return TK_RANK_MAX;
 }
 
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {
@@ -235,11 +238,10 @@ TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t p
 }
 
 // ------------------------------------------------------------------------------------------
-// long piece: [w0, e) does not fit a window.  Returns false if the document must be deferred
-// to the second pass (a miss that needs scratch memory and HAS_SCRATCH is false).
+// pass 2, one piece [w0, e) of any length: whole-piece lookup (wave-wide polynomial hash for
+// pieces of >= 9 bytes), and on a miss the wave-cooperative merge over scratch memory.
 // ------------------------------------------------------------------------------------------
-template <bool HAS_SCRATCH>
-TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e,
+TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e,
                           uint32_t* out, uint32_t& cursor, uint32_t* scratch) {
     const TkTablesView& t = a.t;
     const uint64_t n = e - w0;
@@ -264,15 +266,16 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         }
         r = tk_probe_long(t, h1, h2, (uint32_t)n, a.bytes + w0);
     }
+    r = wv_first(r);
     if (r != TK_RANK_MAX) {
         if (lane == 0) out[cursor] = r + t.num_special;
         cursor += 1;
-        return true;
+        return;
     }
-    if (!HAS_SCRATCH) return false;
 
     // ---- wave-cooperative merge over scratch: tok | prk | nxt | prv | bmin(u64) ----
     const uint32_t nn = (uint32_t)n;
+    if (a.dbg_mark && lane == 0) { a.dbg_mark[0] = 1u; a.dbg_mark[1] = nn; }
     const uint32_t nb = (nn + 63u) / 64u;
     uint32_t* tok = scratch;
     uint32_t* prk = tok + nn;
@@ -288,6 +291,7 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         prv[i] = i ? i - 1u : TK_NONE;
     }
     wv_sync();
+    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 2u;
     for (uint32_t blk = 0; blk < nb; ++blk) {
         uint32_t i = blk * 64u + (uint32_t)lane;
         uint32_t rk = i < nn ? prk[i] : TK_RANK_MAX;
@@ -296,14 +300,16 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
     }
     wv_sync();
-    for (;;) {
+    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 3u;
+    for (uint32_t merges = 0; merges < nn; ++merges) {  // at most nn - 1 merges can happen
+        if (a.dbg_mark && lane == 0) a.dbg_mark[2] = merges;
         uint64_t best = ~0ull;
         for (uint32_t bq = (uint32_t)lane; bq < nb; bq += 64u) {
             uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
             best = v < best ? v : best;
         }
         best = tk_wave_min64(best, lane);
-        if (best == ~0ull) break;
+        if (wv_ballot(best != ~0ull) == 0) break;  // decided on a ballot => a scalar branch
         const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
         const uint32_t j = nxt[i];
         const uint32_t k = nxt[j];
@@ -319,9 +325,10 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         }
         wv_sync();
         uint32_t blks[3] = {i / 64u, j / 64u, (p != TK_NONE) ? p / 64u : i / 64u};
+        const bool skip1 = wv_ballot(blks[1] != blks[0]) == 0;
+        const bool skip2 = wv_ballot(blks[2] != blks[0] && blks[2] != blks[1]) == 0;
         for (int q = 0; q < 3; ++q) {
-            if (q == 1 && blks[1] == blks[0]) continue;
-            if (q == 2 && (blks[2] == blks[0] || blks[2] == blks[1])) continue;
+            if ((q == 1 && skip1) || (q == 2 && skip2)) continue;
             uint32_t x = blks[q] * 64u + (uint32_t)lane;
             uint32_t rk = x < nn ? prk[x] : TK_RANK_MAX;
             uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
@@ -330,6 +337,7 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         }
         wv_sync();
     }
+    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 5u;
     for (uint32_t blk = 0; blk < nb; ++blk) {
         uint32_t i = blk * 64u + (uint32_t)lane;
         uint32_t tv = i < nn ? tok[i] : TK_DEAD;
@@ -337,16 +345,19 @@ TK_DEV bool tk_long_piece(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         if (tv != TK_DEAD) out[cursor + (uint32_t)tk_popc64(am & tk_lowmask(lane))] = tv + t.num_special;
         cursor += (uint32_t)tk_popc64(am);
     }
-    return true;
+    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 6u;
 }
 
 // ------------------------------------------------------------------------------------------
 // one document
 // ------------------------------------------------------------------------------------------
-template <bool HAS_SCRATCH>
-TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkPolyPow& pw, uint32_t* scratch) {
+// MODE 0: pass 1 (a document whose first unfinished piece does not end inside a window is handed
+//         to pass 2: return false);  MODE 2: split only (tk_split_batch), long pieces are skipped
+//         over with the sequential matcher.
+template <int MODE>
+TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkPolyPow& pw) {
     const TkTablesView& t = a.t;
-    const uint64_t s0 = a.doc_offs[d], s1 = a.doc_offs[d + 1];
+    const uint64_t s0 = wv_first64(a.doc_offs[d]), s1 = wv_first64(a.doc_offs[d + 1]);
     uint32_t* out = a.staging + s0 + 2 * d;
     uint32_t cursor = 0;
     if (a.add_bos) {
@@ -366,7 +377,7 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             uint32_t nominal = b0 < 0xC0u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : b0 < 0xF8u ? 4u : 1u;
             uint64_t csraw = wv_ballot(lane < nv && ((b0 & 0xC0u) != 0x80u || lane == 0));
             int last = tk_msb64(csraw);
-            uint32_t nl = wv_shfl(nominal, last);
+            uint32_t nl = wv_first(wv_shfl(nominal, last));
             if (last + (int)nl > nv && last > 0) nv = last;
             if (lane >= nv) b0 = 0u;
         }
@@ -486,13 +497,9 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             const int estar = tk_msb64(cert);
             if (estar == 0) {
                 // the first piece does not end inside the window
-                const uint64_t e = tk_match_end(t, a.bytes, w0, s1);
-                if (a.dbg_starts) {
-                    for (uint64_t q = w0 + (uint64_t)lane; q < e; q += 64) a.dbg_starts[q] = (q == w0);
-                }
-                if (!a.split_only) {
-                    if (!tk_long_piece<HAS_SCRATCH>(a, pw, lane, w0, e, out, cursor, scratch)) return false;
-                }
+                if (MODE != 2) return false;
+                const uint64_t e = wv_first64(tk_match_end(t, a.bytes, w0, s1));
+                for (uint64_t q = w0 + (uint64_t)lane; q < e; q += 64) a.dbg_starts[q] = (q == w0);
                 w0 = e;
                 continue;
             }
@@ -500,8 +507,8 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             PSp = cert & ~(1ull << estar);
         }
         const bool inreg = lane < region_end;
-        if (a.dbg_starts && inreg) a.dbg_starts[w0 + lane] = tk_bit(PSp, lane);
-        if (a.split_only) {
+        if (MODE == 2) {
+            if (inreg) a.dbg_starts[w0 + lane] = tk_bit(PSp, lane);
             w0 += (uint64_t)region_end;
             continue;
         }
@@ -562,7 +569,7 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             uint32_t prank = TK_RANK_MAX;
             if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
             const int sl = pe - 1 < 63 ? pe - 1 : 63;
-            for (;;) {
+            for (int round = 0; round < 64; ++round) {  // a window holds at most 63 merges per piece
                 const uint32_t key = prank == TK_RANK_MAX ? 0xFFFFFFFFu : ((prank << 6) | (uint32_t)lane);
                 uint32_t m = key;
                 for (int dd = 1; dd < 64; dd <<= 1) {
@@ -599,7 +606,7 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         cursor += (uint32_t)tk_popc64(Tm);
         w0 += (uint64_t)region_end;
     }
-    if (!a.split_only) {
+    if (MODE != 2) {
         if (a.add_eos) {
             if (lane == 0) out[cursor] = t.eos_id;
             cursor += 1;
@@ -610,28 +617,60 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
 }
 
 // ------------------------------------------------------------------------------------------
+// pass 2: one deferred document, piece by piece (sequential matcher + tk_piece_coop)
+// ------------------------------------------------------------------------------------------
+TK_DEV void tk_encode_doc_seq(const TkEncodeArgs& a, uint64_t d, int lane, const TkPolyPow& pw, uint32_t* scratch) {
+    const TkTablesView& t = a.t;
+    const uint64_t s0 = wv_first64(a.doc_offs[d]), s1 = wv_first64(a.doc_offs[d + 1]);
+    uint32_t* out = a.staging + s0 + 2 * d;
+    uint32_t cursor = 0;
+    if (a.add_bos) {
+        if (lane == 0) out[0] = t.bos_id;
+        cursor = 1;
+    }
+    uint64_t w0 = s0;
+    while (w0 < s1) {
+        const uint64_t e = wv_first64(tk_match_end(t, a.bytes, w0, s1));
+        tk_piece_coop(a, pw, lane, w0, e, out, cursor, scratch);
+        w0 = e;
+    }
+    if (a.add_eos) {
+        if (lane == 0) out[cursor] = t.eos_id;
+        cursor += 1;
+    }
+    if (lane == 0) a.counts[d] = cursor;
+}
+
+// ------------------------------------------------------------------------------------------
 // one wave: pull documents from the work queue until it is empty
 // ------------------------------------------------------------------------------------------
-template <bool HAS_SCRATCH>
+// MODE 0: pass 1 over all documents; MODE 1: pass 2 over todo_list; MODE 2: split only
+template <int MODE>
 TK_DEV void tk_encode_wave(const TkEncodeArgs& a, int lane, uint64_t wave_id) {
     const TkPolyPow pw = tk_poly_pow(a.t, lane);
-    uint32_t* scratch = HAS_SCRATCH ? a.scratch + wave_id * a.scratch_words_per_wave : nullptr;
-    const uint64_t total = HAS_SCRATCH ? (uint64_t)a.n_todo : a.n_docs;
-    const uint32_t chunk = HAS_SCRATCH ? 1u : TK_DOC_CHUNK;
+    uint32_t* scratch = MODE == 1 ? a.scratch + wave_id * a.scratch_words_per_wave : nullptr;
+    const uint64_t total = MODE == 1 ? (uint64_t)a.n_todo : a.n_docs;
+    const uint32_t chunk = MODE == 1 ? 1u : TK_DOC_CHUNK;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = wv_atomic_add(a.work_counter, chunk);
-        base = wv_shfl(base, 0);
+        // Every lane takes part in the fetch (the compiler folds it into ONE atomic of 64*chunk and
+        // hands lane i the value old + i*chunk), so no lane-dependent branch feeds the loop condition:
+        // with `if (lane == 0) base = atomicAdd(..)` the optimizer threaded lanes 1..63 around the
+        // atomic and they re-ran the loop without lane 0 (observed on gfx950, ROCm 7.2).
+        const uint32_t ticket = wv_first(wv_atomic_add_all(a.work_counter, chunk));
+        const uint32_t base = ticket / 64u;  // scalar: document index, offsets and the window loop are wave-uniform
         if ((uint64_t)base >= total) break;
         const uint64_t hi = (uint64_t)base + chunk < total ? (uint64_t)base + chunk : total;
         for (uint64_t q = base; q < hi; ++q) {
-            const uint64_t d = HAS_SCRATCH ? (uint64_t)a.todo_list[q] : q;
-            const bool ok = tk_encode_doc<HAS_SCRATCH>(a, d, lane, pw, scratch);
-            if (!ok && lane == 0) {
-                // pass 1 only: the document needs the scratch-backed merge
-                a.counts[d] = 0;
-                const uint32_t slot = wv_atomic_add(a.defer_count, 1u);
-                a.defer_list[slot] = (uint32_t)d;
+            if (MODE == 1) {
+                tk_encode_doc_seq(a, (uint64_t)wv_first(a.todo_list[q]), lane, pw, scratch);
+            } else {
+                const bool ok = tk_encode_doc<MODE>(a, q, lane, pw);
+                if (!ok && lane == 0) {
+                    // pass 1 only: the document has a piece that does not fit a window
+                    a.counts[q] = 0;
+                    const uint32_t slot = wv_atomic_add(a.defer_count, 1u);
+                    a.defer_list[slot] = (uint32_t)q;
+                }
             }
         }
     }

@@ -18,6 +18,7 @@ struct TkEncodeArgs {
     const uint32_t* todo_list;  // pass 2: the documents to process
     uint32_t n_todo;
     uint8_t* dbg_starts;        // optional: per-byte piece-start flags (tk_split_batch)
+    volatile uint32_t* dbg_mark; // optional: progress marks of the long-piece merge (debug builds of the host)
     uint32_t* scratch;          // pass 2: per-wave scratch for the cooperative merge
     uint64_t scratch_words_per_wave;
     int add_bos, add_eos;

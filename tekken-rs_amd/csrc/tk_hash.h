@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define TK_HD __host__ __device__ __forceinline__
 #else
 #define TK_HD inline

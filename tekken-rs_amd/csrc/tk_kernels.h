@@ -6,8 +6,9 @@
 
 #include "tk_encode_impl_args.h"
 
-// pass 1 (no scratch) / pass 2 (scratch-backed long-piece merge); n_waves = waves launched
-hipError_t tk_launch_encode(const TkEncodeArgs& args, bool pass2, uint32_t n_waves, hipStream_t s);
+// mode 0: pass 1; mode 1: pass 2 (scratch-backed, every launched wave owns a scratch slice);
+// mode 2: split only.  n_waves = waves launched (rounded up to whole 4-wave blocks)
+hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves, hipStream_t s);
 
 // counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
 // ceil(n/2048)+1 u64.  offs[n] (= total) is also what the host reads back.
@@ -20,6 +21,10 @@ hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, 
 // UTF-8 validation of every document; *d_bad receives the number of invalid documents
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s);
+
+// max document length over the deferred documents (atomicMax into *d_out, which must be zeroed)
+hipError_t tk_launch_defer_maxlen(const uint32_t* defer_list, uint32_t n, const uint64_t* doc_offs, uint32_t* d_out,
+                                  hipStream_t s);
 
 // self-test of the wave primitives (DPP shifts, bpermute); writes 0 to *d_fail when all pass
 hipError_t tk_launch_wave_selftest(uint32_t* d_fail, hipStream_t s);

@@ -1,7 +1,8 @@
 // tk_kernels.hip -- gfx950 kernels of the batch tokenization path.
 //
-//   tk_encode_kernel<false>   pass 1: every document, one wave per document at a time
-//   tk_encode_kernel<true>    pass 2: the few documents whose long pieces need scratch memory
+//   tk_encode_kernel<0>       pass 1: every document, one wave per document at a time
+//   tk_encode_kernel<1>       pass 2: the few documents with a piece that does not fit a window
+//   tk_encode_kernel<2>       split only (tk_split_batch)
 //   tk_scan_*                 per-document id counts -> output offsets (exclusive scan, u64)
 //   tk_compact_kernel         staging -> packed ids (the reference's Vec<u32> per document,
 //                             concatenated; ids already carry +num_special and BOS/EOS:
@@ -19,18 +20,19 @@
 
 #define TK_BLOCK 256
 
-template <bool HAS_SCRATCH>
+template <int MODE>
 __global__ __launch_bounds__(TK_BLOCK) void tk_encode_kernel(TkEncodeArgs a) {
     const int lane = wv_lane();
     const uint64_t wave_id = (uint64_t)blockIdx.x * (TK_BLOCK / 64) + (threadIdx.x >> 6);
-    tk_encode_wave<HAS_SCRATCH>(a, lane, wave_id);
+    tk_encode_wave<MODE>(a, lane, wave_id);
 }
 
-hipError_t tk_launch_encode(const TkEncodeArgs& args, bool pass2, uint32_t n_waves, hipStream_t s) {
+hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves, hipStream_t s) {
     const uint32_t blocks = (n_waves + (TK_BLOCK / 64) - 1) / (TK_BLOCK / 64);
     if (blocks == 0) return hipSuccess;
-    if (pass2) hipLaunchKernelGGL(tk_encode_kernel<true>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
-    else hipLaunchKernelGGL(tk_encode_kernel<false>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    if (mode == 1) hipLaunchKernelGGL(tk_encode_kernel<1>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    else if (mode == 2) hipLaunchKernelGGL(tk_encode_kernel<2>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    else hipLaunchKernelGGL(tk_encode_kernel<0>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
     return hipGetLastError();
 }
 
@@ -198,6 +200,24 @@ hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, ui
     uint64_t blocks = (n_docs + (TK_BLOCK / 64) - 1) / (TK_BLOCK / 64);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(tk_validate_kernel, dim3((uint32_t)blocks), dim3(TK_BLOCK), 0, s, bytes, doc_offs, n_docs, d_bad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// longest deferred document (sizes the pass-2 scratch)
+// ------------------------------------------------------------------------------------------
+__global__ void tk_defer_maxlen_kernel(const uint32_t* defer_list, uint32_t n, const uint64_t* doc_offs, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t d = defer_list[i];
+    const uint64_t len = doc_offs[d + 1] - doc_offs[d];
+    atomicMax(out, (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len));
+}
+
+hipError_t tk_launch_defer_maxlen(const uint32_t* defer_list, uint32_t n, const uint64_t* doc_offs, uint32_t* d_out,
+                                  hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_defer_maxlen_kernel, dim3((n + 255) / 256), dim3(256), 0, s, defer_list, n, doc_offs, d_out);
     return hipGetLastError();
 }
 

@@ -15,6 +15,12 @@ TK_DEV uint32_t wv_shfl(uint32_t v, int src) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
 }
 
+// value of `v` in the first active lane, as a wave-uniform (scalar) value
+TK_DEV uint32_t wv_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+TK_DEV uint64_t wv_first64(uint64_t v) {
+    return ((uint64_t)wv_first((uint32_t)(v >> 32)) << 32) | (uint64_t)wv_first((uint32_t)v);
+}
+
 // lane i receives lane i+1's value, lane 63 receives 0   (DPP wave_shl:1)
 TK_DEV uint32_t wv_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
@@ -25,12 +31,17 @@ TK_DEV uint32_t wv_dn1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
 }
 
-// orders this wave's earlier global stores before its later loads (one wave only)
+// orders this wave's earlier global stores before its later loads: the stores must have been
+// acknowledged (s_waitcnt vmcnt(0)) before a lane reads what another lane of the wave wrote
 TK_DEV void wv_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
 
+// executed by ONE lane (inside a lane-predicated block whose result feeds no wave primitive)
 TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+
+// executed by ALL 64 lanes in uniform control flow: *p += 64*v, lane i receives old + i*v
+TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
 #endif

@@ -53,7 +53,8 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
     a.t = T.host_view();
 
     uint64_t ops = 0;
-    tkemu::run_wave([&](int lane) { tk_encode_wave<false>(a, lane, 0); });
+    if (split_only) tkemu::run_wave([&](int lane) { tk_encode_wave<2>(a, lane, 0); });
+    else tkemu::run_wave([&](int lane) { tk_encode_wave<0>(a, lane, 0); });
     ops += tkemu::g_wave->n_ops;
     if (n_deferred) *n_deferred = defer_count;
     if (defer_count) {
@@ -65,7 +66,7 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
         work_counter = 0;
         uint32_t dc2 = 0;
         a.defer_count = &dc2;
-        tkemu::run_wave([&](int lane) { tk_encode_wave<true>(a, lane, 0); });
+        tkemu::run_wave([&](int lane) { tk_encode_wave<1>(a, lane, 0); });
         if (dc2 != 0) { g_err = "pass 2 deferred a document"; return TK_ERR_RUNTIME; }
     }
     if (n_ops) *n_ops = tkemu::g_wave->n_ops;

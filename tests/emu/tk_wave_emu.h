@@ -21,10 +21,11 @@
 #include <vector>
 
 #define TK_DEV static inline
+#define TK_DEV_NOINLINE static
 
 namespace tkemu {
 
-enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC, OP_FIRST, OP_ATOMIC };
 
 struct Wave {
     ucontext_t sched;
@@ -131,6 +132,17 @@ TK_DEV uint32_t wv_shfl(uint32_t v, int src) {
     return tkemu::g_wave->snap_u32[src];
 }
 
+// all lanes are active in the emulator: the first active lane is lane 0
+TK_DEV uint32_t wv_first(uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    w->dep_u32[w->cur] = v;
+    tkemu::yield_op(tkemu::OP_FIRST);
+    return tkemu::g_wave->snap_u32[0];
+}
+TK_DEV uint64_t wv_first64(uint64_t v) {
+    return ((uint64_t)wv_first((uint32_t)(v >> 32)) << 32) | (uint64_t)wv_first((uint32_t)v);
+}
+
 TK_DEV uint32_t wv_up1(uint32_t v) {
     tkemu::Wave* w = tkemu::g_wave;
     int lane = w->cur;
@@ -153,6 +165,17 @@ TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) {
     uint32_t old = *p;
     *p = old + v;
     return old;
+}
+
+TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    int lane = w->cur;
+    if (lane == 0) {  // lanes run in order 0..63 between two primitives
+        w->dep_u32[0] = *p;
+        *p += 64u * v;
+    }
+    tkemu::yield_op(tkemu::OP_ATOMIC);
+    return tkemu::g_wave->snap_u32[0] + (uint32_t)lane * v;
 }
 
 #endif

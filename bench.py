@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- input MB/s tokenized on MI355X for the tekken-rs `Tekkenizer::encode` hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (split + merge + emit, ids packed in document order) over one
+batch of synthetic documents already resident in HBM:
+  N = 1 : BASELINE.json configs[1] = 1 M x 512-byte ASCII documents (G-ascii)
+  N > 1 : configs[3] shape = 1 M x 512-byte documents PER GPU (weak scaling: 8 M over 8 GPUs),
+          contiguous shards, plus the single RCCL gather of the id buffers to rank 0 inside the step.
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (tk_encode_kernel<0>) against the HBM roofline:
+                  algorithmic bytes (N_in + 8(D+1) + 4 T_out + 8(D+1)) per launch divided by
+                  its mean duration measured live with HIP events on the launch stream
+  cpu_baseline -- the CPU oracle (a restatement, "port": the reference is Rust and cannot be built
+                  here) timed single-thread on this box's host cores on the same documents
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--doc-len", type=int, default=512)
+    ap.add_argument("--kind", default="ascii", choices=["ascii", "mixed", "zipf"])
+    ap.add_argument("--cpu-passes", type=int, default=2, help="oracle passes over the CPU sample (0 = skip)")
+    ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
+    ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import corpus
+    import synth_vocab as sv
+    tk = importlib.import_module("tekken-rs_amd")
+    par = importlib.import_module("tekken-rs_amd.parallel")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- vocabulary (real tekken.json if TEKKEN_JSON is set, else the seeded synthetic one) ----
+    vocab_path = args.vocab or sv.ensure_default()
+    vocab_kind = "tekken.json" if args.vocab else "synthetic-130072"
+    tokz = tk.Tekkenizer.from_file(vocab_path, device=local_rank)  # loader + table build + upload
+    eng = tokz.engine()
+
+    # ---- this rank's shard of the corpus, generated in place (documents are seeded per index) ----
+    seed = corpus.BASE_SEED + (1 if not distributed else 3)
+    data, offs = corpus.generate(args.kind, args.docs, args.doc_len, seed=seed, first_doc=rank * args.docs)
+    n_docs, n_bytes = args.docs, int(offs[-1])
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+
+    enc_ms = []
+    pipe_ms = []
+    n_ids_local = 0
+    gathered = None
+
+    def step():
+        nonlocal n_ids_local, gathered
+        v_ids, v_oo = eng.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, True, True, stream)
+        n_ids_local = v_ids.__cuda_array_interface__["shape"][0]
+        t = eng.last_timing()
+        enc_ms.append(t["encode_kernel_ms"])
+        pipe_ms.append(t["pipeline_ms"])
+        if distributed:
+            ids = torch.as_tensor(v_ids, device="cuda")
+            oo = torch.as_tensor(v_oo, device="cuda")
+            gathered = par.gather_ids(ids, oo[1:] - oo[:-1], dst=0)
+        return v_ids, v_oo
+
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    enc_ms.clear()
+    pipe_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        v_ids, v_oo = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([n_bytes, n_ids_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        total_bytes, total_ids = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_bytes, total_ids = n_bytes, n_ids_local
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_bytes / 1e6 / (elapsed / args.steps)
+        # roofline of the dominant kernel on THIS rank: algorithmic bytes per launch / mean launch duration
+        bytes_alg = n_bytes + 8 * (n_docs + 1) + 4 * n_ids_local + 8 * (n_docs + 1)
+        k_ms = float(np.mean(enc_ms))
+        achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("tk_encode_kernel_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "input MB/s tokenized (whole node)", "value": round(value, 1), "unit": "MB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d x %d-byte %s docs per GPU (%s)" % (
+                n_docs, args.doc_len, {"ascii": "ASCII (G-ascii)", "mixed": "mixed UTF-8 (G-mixed)", "zipf": "Zipf-length"}[args.kind],
+                "BASELINE configs[1]" if not distributed else "BASELINE configs[3] shape, RCCL gather to rank 0 in the step"),
+                "docs_total": n_docs * world, "input_bytes_total": total_bytes, "ids_total": total_ids,
+                "vocab": vocab_kind, "add_bos": True, "add_eos": True, "sharding": "contiguous whole documents per GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "tk_encode_kernel<0>", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+                         "pipeline_ms": round(float(np.mean(pipe_ms)), 4)},
+            "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
+        }
+        if not distributed and args.cpu_passes > 0:
+            out.update(cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes))
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    tokz.close()
+
+
+def cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes):
+    """The oracle, single thread, on the same documents (the checker timed as the CPU baseline) and the
+    bit-exact comparison of the GPU ids with it."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth_vocab as sv
+    import tk_oracle
+    toks, ns, bos, eos = sv.load_tokens(vocab_path)
+    orc = tk_oracle.Oracle(toks, ns, bos, eos)
+    m = min(args.cpu_sample_docs, len(offs) - 1)
+    sub, sub_offs = data[:int(offs[m])], offs[:m + 1]
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_passes):
+        eids, eoo = orc.encode_batch(sub, sub_offs, True, True, threads=1)
+    dt = (time.perf_counter() - t0) / args.cpu_passes
+    cpu_mbs = int(offs[m]) / 1e6 / dt
+    ids = torch.as_tensor(v_ids, device="cuda").cpu().numpy().view(np.uint32)
+    oo = torch.as_tensor(v_oo, device="cuda").cpu().numpy().astype(np.uint64)
+    exact = bool(np.array_equal(oo[:m + 1], eoo) and np.array_equal(ids[:int(oo[m])], eids))
+    return {"cpu_baseline": {"value": round(cpu_mbs, 1), "unit": "MB/s", "cores": 1, "kind": "port",
+                             "sample": "%d docs (%d bytes) of the same workload, %d passes of %.1f s, oracle/tk_oracle.c single thread; host has %d cores"
+                                       % (m, int(offs[m]), args.cpu_passes, dt, os.cpu_count() or 0)},
+            "bit_exact_vs_cpu": exact, "fnv1a_ids": "%016x" % tk_oracle.fnv1a(ids)}
+
+
+if __name__ == "__main__":
+    main()

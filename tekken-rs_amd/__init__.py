@@ -174,6 +174,16 @@ def _take_result(res):
     return ids, offs
 
 
+class DeviceView:
+    """Zero-copy view of a context-owned device buffer for array libraries that understand
+    `__cuda_array_interface__` (e.g. `torch.as_tensor(view, device="cuda")`).  Valid until the next
+    call on the owning context."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
 class Engine:
     """Engine-level context: the replacement for CoreBPE (reference src/tekkenizer.rs:125, 384-386)."""
 
@@ -234,6 +244,11 @@ class Engine:
         if rc != TK_OK:
             raise self._err(rc)
         return d_ids.value, d_oo.value, int(n.value)
+
+    def encode_batch_device_views(self, d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos=True, add_eos=True, stream=0):
+        """Same, returning (ids view as int32[n_ids], offsets view as int64[n_docs+1])."""
+        p_ids, p_oo, n = self.encode_batch_device(d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos, add_eos, stream)
+        return DeviceView(p_ids, n, "<i4"), DeviceView(p_oo, n_docs + 1, "<i8")
 
     def last_timing(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)

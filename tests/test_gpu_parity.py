@@ -1,0 +1,198 @@
+"""Parity tests proper: the HIP path, called through the C ABI (include/tekken_hip.h), against the
+oracle on the same seeded inputs -- bit-exact (integer work, no tolerance).
+
+Small sizes compare every id with the oracle; the full BASELINE size (1 M x 512 B) is checked
+through size-independent properties (bytes of the emitted tokens concatenate back to the input,
+determinism, checksum of a sample vs the oracle).  Nothing here reads /root/reference.
+"""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+import corpus
+import helpers
+import tk_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_small(tk, test_vocab):
+    e = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_bench(tk, bench_vocab):
+    e = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
+    yield e
+    e.close()
+
+
+def check_batch(eng, orc, data, offs, bos=True, eos=True):
+    ids, oo = eng.encode_batch(data, offs, bos, eos)
+    eids, eoo = orc.encode_batch(data, offs, bos, eos, threads=8)
+    if not (np.array_equal(oo, eoo) and np.array_equal(ids, eids)):
+        for d in range(len(offs) - 1):
+            a = ids[int(oo[d]):int(oo[d + 1])]
+            b = eids[int(eoo[d]):int(eoo[d + 1])]
+            assert a.tolist() == b.tolist(), (d, bytes(data[int(offs[d]):int(offs[d + 1])])[:120])
+        raise AssertionError("offset arrays differ")
+    return ids, oo
+
+
+def test_library_loaded_is_the_hip_one(tk, eng_small):
+    import ctypes
+    assert tk.lib()._name.endswith("libtekken_hip.so")
+    assert isinstance(eng_small._h, ctypes.c_void_p) and eng_small._h.value
+
+
+def test_small_vocab_known_answer_via_tokenizer(tk, golden, small_vocab):
+    """Tekkenizer::from_file -> encode -> decode on the reference's small-vocab construction."""
+    from test_host_tokenizer import model
+    t = tk.Tekkenizer.from_json(json.dumps(model(small_vocab["tokens"])), device=0)
+    for text, bos, eos, ids in golden["ref"]["small_vocab"]["cases"]:
+        assert t.encode(text, bos, eos) == ids
+    ids = t.encode("hello world", True, True)
+    assert t.decode(ids, tk.SpecialTokenPolicy.Ignore) == "hello world"
+    assert t.encode_batch(["hello world", "", "world"], False, False) == [[266, 42, 129, 121, 124, 118, 110], [], [267]]
+    t.close()
+
+
+def test_reference_vectors_on_consistent_vocab(tk, golden):
+    import ref_consistent_vocab as rcv
+    toks = rcv.build(golden["ref"])
+    e = tk.Engine(toks, 1000, 1, 2, device=0)
+    texts = [t for t, _ in golden["ref"]["encode"]]
+    got = e.encode_docs([t.encode("utf-8") for t in texts], False, False)
+    for (t, ids), g in zip(golden["ref"]["encode"], got):
+        assert g == ids, t
+    e.close()
+
+
+def test_split_matches_golden(eng_small, golden):
+    cases = golden["split"]["cases"]
+    got = eng_small.split_docs([c["text"].encode("utf-8") for c in cases])
+    for c, s in zip(cases, got):
+        assert s == c["starts"], c["text"]
+
+
+@pytest.mark.parametrize("bos,eos", [(True, True), (False, False), (True, False), (False, True)])
+def test_mixed_docs_small_vocab(eng_small, test_vocab, bos, eos):
+    orc = helpers.oracle_for(test_vocab)
+    docs = helpers.mixed_docs(200, 60, 300, max_len=40000) + helpers.random_unicode_docs(500)
+    data = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    check_batch(eng_small, orc, data, offs, bos, eos)
+
+
+@pytest.mark.parametrize("kind,n,dl,seed", [("ascii", 20000, 512, 1), ("mixed", 4000, 2048, 2), ("zipf", 6000, 0, 4),
+                                              ("ascii", 1000, 64, 0)])
+def test_baseline_shapes_bench_vocab(eng_bench, bench_vocab, kind, n, dl, seed):
+    """Reduced-size versions of the BASELINE.json configs (C1..C5 shapes), every id compared."""
+    orc = helpers.oracle_for(bench_vocab)
+    data, offs = corpus.generate(kind, n, dl, seed=corpus.BASE_SEED + seed)
+    check_batch(eng_bench, orc, data, offs)
+    if kind == "zipf":
+        assert eng_bench.last_stats()["long_docs"] > 0  # the long-piece second pass ran
+
+
+def test_edge_batches(eng_small, test_vocab):
+    orc = helpers.oracle_for(test_vocab)
+    # empty batch, only-empty docs, one empty doc between others
+    ids, oo = eng_small.encode_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(ids) == 0 and oo.tolist() == [0]
+    assert eng_small.encode_docs([b"", b"", b""], True, True) == [[1, 2]] * 3
+    assert eng_small.encode_docs([b"", b""], False, False) == [[], []]
+    assert eng_small.encode_docs([b"a", b"", b"b"], True, False) == [orc.encode(b"a", True, False), [1],
+                                                                    orc.encode(b"b", True, False)]
+    # maximum sizes of the configs: a 32 KiB single letter run, a 32 KiB white-space run, a 300 KB document
+    rng = np.random.default_rng(5)
+    big = [bytes(rng.integers(97, 123, 32768, dtype=np.uint8)), b" " * 20000 + b"\n" + b" " * 12767,
+           b"the quick brown fox " * 15000, ("中文" * 8000).encode(), b"x" + b"\n" * 5000]
+    for doc in big:
+        assert eng_small.encode_docs([doc], True, True)[0] == orc.encode(doc, True, True), doc[:40]
+
+
+def test_utf8_validation(tk, eng_small):
+    good = ["ok", "é中🚀"]
+    eng_small.encode_docs([g.encode() for g in good], validate_utf8=True)
+    for bad in (b"\xff", b"a\xc3", b"\xe2\x82", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"ab\x80cd"):
+        with pytest.raises(tk.TokenizerError) as e:
+            eng_small.encode_docs([b"fine", bad], validate_utf8=True)
+        assert e.value.code == tk.TK_ERR_INVALID_UTF8, bad
+
+
+def test_invalid_table_rejected(tk, small_vocab):
+    toks = list(small_vocab["tokens"])
+    with pytest.raises(tk.TokenizerError) as e:
+        tk.Engine(toks[:200], 10, 1, 2)
+    assert e.value.kind == "InvalidConfig"
+    toks[257] = b"hello"
+    with pytest.raises(tk.TokenizerError) as e:
+        tk.Engine(toks, 10, 1, 2)
+    assert e.value.kind == "InvalidConfig"
+
+
+def test_concurrent_calls_on_one_context(eng_small, test_vocab):
+    """The reference's Tekkenizer is Sync (tests/test_tokenizer_output.rs:5-12): one context, many threads."""
+    orc = helpers.oracle_for(test_vocab)
+    docs = helpers.mixed_docs(50, 10, 30)
+    exp = [orc.encode(d, True, True) for d in docs]
+    errs = []
+
+    def run():
+        try:
+            for _ in range(5):
+                assert eng_small.encode_docs(docs, True, True) == exp
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=run) for _ in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:1]
+
+
+def test_device_resident_entry_and_full_size_properties(tk, eng_bench, bench_vocab):
+    """BASELINE config C2 at full size (1 M x 512 B) with inputs resident in HBM."""
+    import torch
+    n_docs = 1_000_000
+    data, offs = corpus.generate("ascii", n_docs, 512, seed=corpus.BASE_SEED + 1)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    sums = []
+    for _ in range(2):
+        v_ids, v_oo = eng_bench.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, len(data), True,
+                                                          True, stream)
+        ids = torch.as_tensor(v_ids, device="cuda")
+        oo = torch.as_tensor(v_oo, device="cuda")
+        ids_h = ids.cpu().numpy().view(np.uint32)
+        oo_h = oo.cpu().numpy().astype(np.uint64)
+        sums.append(tk_oracle.fnv1a(ids_h))
+    assert sums[0] == sums[1]  # deterministic
+    assert int(oo_h[-1]) == len(ids_h) and np.all(np.diff(oo_h.astype(np.int64)) >= 2)
+    ns = bench_vocab["num_special"]
+    # size-independent property: the bytes of the emitted tokens concatenate back to the input
+    tok_len = np.array([len(t) for t in bench_vocab["tokens"]], dtype=np.int64)
+    body = ids_h[ids_h >= ns]
+    assert int(tok_len[body - ns].sum()) == len(data)
+    assert len(ids_h) - len(body) == 2 * n_docs  # exactly one BOS and one EOS per document
+    first = oo_h[:-1].astype(np.int64)
+    last = oo_h[1:].astype(np.int64) - 1
+    assert np.all(ids_h[first] == bench_vocab["bos"]) and np.all(ids_h[last] == bench_vocab["eos"])
+    # a sample of documents against the oracle, id for id (checksum of checksums)
+    orc = helpers.oracle_for(bench_vocab)
+    for lo in (0, 500_000, 990_000):
+        hi = lo + 5000
+        sub_offs = offs[lo:hi + 1] - offs[lo]
+        eids, _ = orc.encode_batch(data[int(offs[lo]):int(offs[hi])], sub_offs, True, True, threads=8)
+        got = ids_h[int(oo_h[lo]):int(oo_h[hi])]
+        assert tk_oracle.fnv1a(got) == tk_oracle.fnv1a(eids)
+    tm = eng_bench.last_timing()
+    assert tm["encode_kernel_ms"] > 0 and tm["pipeline_ms"] >= tm["encode_kernel_ms"]

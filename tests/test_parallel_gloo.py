@@ -1,0 +1,80 @@
+"""The N>1 path (byte-balanced sharding + variable-length gather to rank 0) with world_size 2 and 3
+on the gloo backend.  The per-rank encoder is the oracle here (this is a CPU test of the
+distributed plumbing, tekken-rs_amd/parallel.py); on the GPU box the same code runs with the HIP
+engine and backend nccl (= RCCL)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import corpus
+    import helpers
+    par = importlib.import_module("tekken-rs_amd.parallel")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v = helpers.small_trained_vocab()
+        orc = helpers.oracle_for(v)
+        data, offs = corpus.generate("zipf", 400, seed=corpus.BASE_SEED + 4)
+
+        def enc(d, o, bos, eos):
+            return orc.encode_batch(d, o, bos, eos)
+
+        ids, oo = par.encode_sharded(enc, data, offs, True, True, dst=0)
+        if rank == 0:
+            eids, eoo = orc.encode_batch(data, offs, True, True)
+            ok = np.array_equal(ids, eids) and np.array_equal(oo, eoo)
+            # empty shard edge: more ranks than documents
+            with open(out_path, "w") as f:
+                f.write("ok" if ok else "mismatch")
+        # a second round where one rank has nothing to send
+        data2, offs2 = data[:int(offs[1])], offs[:2]
+        ids2, oo2 = par.encode_sharded(enc, data2, offs2, False, False, dst=0)
+        if rank == 0:
+            e2, eo2 = orc.encode_batch(data2, offs2, False, False)
+            if not (np.array_equal(ids2, e2) and np.array_equal(oo2, eo2)):
+                with open(out_path, "w") as f:
+                    f.write("mismatch-single-doc")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_encode_gathers_in_document_order(world, tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_shard_by_bytes_balances_bytes():
+    par = importlib.import_module("tekken-rs_amd.parallel")
+    rng = np.random.default_rng(0)
+    lens = np.concatenate([rng.integers(16, 200, 1000), [30000, 30000], rng.integers(16, 200, 1000)])
+    offs = np.zeros(len(lens) + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    for world in (1, 2, 4, 8):
+        cuts = par.shard_by_bytes(offs, world)
+        assert cuts[0] == 0 and cuts[-1] == len(lens) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        per = [int(offs[cuts[r + 1]]) - int(offs[cuts[r]]) for r in range(world)]
+        assert max(per) - min(per) <= 2 * 30000 + 200
+    assert par.shard_by_bytes(np.zeros(1, np.uint64), 4) == [0, 0, 0, 0, 0]

@@ -79,6 +79,18 @@ TK_DEV uint32_t tk_probe_short(const TkTablesView& t, uint32_t lo, uint32_t hi, 
     return TK_RANK_MAX;
 }
 
+TK_DEV uint32_t tk_probe_mid(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    uint32_t s = tk_mid_hash(k0, k1, k2, k3, len) & t.mid_mask;
+    for (uint32_t tries = 0; tries <= t.mid_mask; ++tries) {
+        const tk_mid_entry* e = t.mid_tab + s;
+        const uint32_t el = e->len;
+        if (el == 0u) return TK_RANK_MAX;
+        if (el == len && e->k[0] == k0 && e->k[1] == k1 && e->k[2] == k2 && e->k[3] == k3) return e->rank;
+        s = (s + 1u) & t.mid_mask;
+    }
+    return TK_RANK_MAX;
+}
+
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so
 // that the result is exact, not probabilistic.
 TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, uint32_t len, const uint8_t* text) {
@@ -252,6 +264,10 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         uint64_t key = 0;
         for (uint64_t k = 0; k < n; ++k) key |= (uint64_t)a.bytes[w0 + k] << (8 * k);
         r = tk_probe_short(t, (uint32_t)key, (uint32_t)(key >> 32), (uint32_t)n);
+    } else if (n <= 16) {
+        uint32_t kk[4] = {0u, 0u, 0u, 0u};
+        for (uint64_t j = 0; j < n; ++j) kk[j >> 2] |= (uint32_t)a.bytes[w0 + j] << (8 * (j & 3));
+        r = tk_probe_mid(t, kk[0], kk[1], kk[2], kk[3], (uint32_t)n);
     } else {
         // H = sum b_j P^(n-1-j), folded 64 bytes at a time: H = H * P^m + (sum b_i P^-i) * P^(m-1)
         uint32_t h1 = 0, h2 = 0;
@@ -526,9 +542,13 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         const uint32_t d4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
         uint32_t d4hi = wv_shfl(d4, lane + 4 < 64 ? lane + 4 : lane);
         if (lane + 4 >= 64) d4hi = 0u;
+        uint32_t d4b = wv_shfl(d4, lane + 8 < 64 ? lane + 8 : lane);    // bytes 8..11 and 12..15 of the
+        uint32_t d4c = wv_shfl(d4, lane + 12 < 64 ? lane + 12 : lane);  // exact 128-bit key of MID pieces
+        if (lane + 8 >= 64) d4b = 0u;
+        if (lane + 12 >= 64) d4c = 0u;
 
         uint32_t h1 = 0, h2 = 0;
-        const uint64_t LONGM = wv_ballot(isstart && len >= 9);
+        const uint64_t LONGM = wv_ballot(isstart && len >= 17);
         if (LONGM) {
             const uint32_t t1 = b0 * pw.ipw1, t2 = b0 * pw.ipw2;
             uint32_t f1 = t1, f2 = t2;
@@ -553,6 +573,11 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
                 if (len <= 4) { hi = 0u; if (len < 4) lo &= (1u << (8 * len)) - 1u; }
                 else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
                 tokv = tk_probe_short(t, lo, hi, (uint32_t)len);
+            } else if (len <= 16) {
+                uint32_t k1 = d4hi, k2 = d4b, k3 = d4c;
+                if (len <= 12) { k3 = 0u; if (len < 12) k2 &= (1u << (8 * (len - 8))) - 1u; }
+                else if (len < 16) k3 &= (1u << (8 * (len - 12))) - 1u;
+                tokv = tk_probe_mid(t, d4, k1, k2, k3, (uint32_t)len);
             } else {
                 tokv = tk_probe_long(t, h1, h2, (uint32_t)len, a.bytes + w0 + lane);
             }

@@ -52,7 +52,7 @@ struct tk_ctx {
     std::string err;
     TkHostTables host;
     TkTablesView dview;
-    DevBuf t_uc1, t_uc2, t_short, t_mid, t_long, t_pair, t_pair2, t_blob;
+    DevBuf t_uc1, t_uc2, t_key, t_long, t_pair, t_pair2, t_blob;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -114,8 +114,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     const TkHostTables& h = c->host;
     if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
         (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||
-        (rc = upload(c, c->t_short, h.short_tab.data(), h.short_tab.size() * sizeof(tk_short_entry))) ||
-        (rc = upload(c, c->t_mid, h.mid_tab.data(), h.mid_tab.size() * sizeof(tk_mid_entry))) ||
+        (rc = upload(c, c->t_key, h.key_tab.data(), h.key_tab.size() * sizeof(tk_key_entry))) ||
         (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
         (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
@@ -124,8 +123,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview = h.host_view();
     c->dview.uc_stage1 = (const uint16_t*)c->t_uc1.p;
     c->dview.uc_stage2 = (const uint32_t*)c->t_uc2.p;
-    c->dview.short_tab = (const tk_short_entry*)c->t_short.p;
-    c->dview.mid_tab = (const tk_mid_entry*)c->t_mid.p;
+    c->dview.key_tab = (const tk_key_entry*)c->t_key.p;
     c->dview.long_tab = (const tk_long_entry*)c->t_long.p;
     c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
     c->dview.pair2 = (const uint32_t*)c->t_pair2.p;
@@ -152,7 +150,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_short, &c->t_mid, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob,
+    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg};
     for (DevBuf* b : bufs) b->release();

@@ -68,25 +68,14 @@ TK_DEV uint32_t tk_uc_class(const TkTablesView& t, uint32_t cp) {
     return (w >> (2u * (cp & 15u))) & 3u;
 }
 
-TK_DEV uint32_t tk_probe_short(const TkTablesView& t, uint32_t lo, uint32_t hi, uint32_t len) {
-    uint32_t s = tk_short_hash(lo, hi, len) & t.short_mask;
-    for (uint32_t tries = 0; tries <= t.short_mask; ++tries) {  // load factor <= 1/2: an empty slot is always met
-        tk_short_entry e = t.short_tab[s];
-        if (e.len == 0u) return TK_RANK_MAX;
-        if (e.len == len && e.key_lo == lo && e.key_hi == hi) return e.rank;
-        s = (s + 1u) & t.short_mask;
-    }
-    return TK_RANK_MAX;
-}
-
-TK_DEV uint32_t tk_probe_mid(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
-    uint32_t s = tk_mid_hash(k0, k1, k2, k3, len) & t.mid_mask;
-    for (uint32_t tries = 0; tries <= t.mid_mask; ++tries) {
-        const tk_mid_entry* e = t.mid_tab + s;
+TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    uint32_t s = tk_key_hash(k0, k1, k2, k3, len) & t.key_mask;
+    for (uint32_t tries = 0; tries <= t.key_mask; ++tries) {
+        const tk_key_entry* e = t.key_tab + s;
         const uint32_t el = e->len;
         if (el == 0u) return TK_RANK_MAX;
         if (el == len && e->k[0] == k0 && e->k[1] == k1 && e->k[2] == k2 && e->k[3] == k3) return e->rank;
-        s = (s + 1u) & t.mid_mask;
+        s = (s + 1u) & t.key_mask;
     }
     return TK_RANK_MAX;
 }
@@ -260,14 +249,10 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
     uint32_t r = TK_RANK_MAX;
     if (n == 1) {
         r = a.bytes[w0];
-    } else if (n <= 8) {
-        uint64_t key = 0;
-        for (uint64_t k = 0; k < n; ++k) key |= (uint64_t)a.bytes[w0 + k] << (8 * k);
-        r = tk_probe_short(t, (uint32_t)key, (uint32_t)(key >> 32), (uint32_t)n);
     } else if (n <= 16) {
         uint32_t kk[4] = {0u, 0u, 0u, 0u};
         for (uint64_t j = 0; j < n; ++j) kk[j >> 2] |= (uint32_t)a.bytes[w0 + j] << (8 * (j & 3));
-        r = tk_probe_mid(t, kk[0], kk[1], kk[2], kk[3], (uint32_t)n);
+        r = tk_probe_key(t, kk[0], kk[1], kk[2], kk[3], (uint32_t)n);
     } else {
         // H = sum b_j P^(n-1-j), folded 64 bytes at a time: H = H * P^m + (sum b_i P^-i) * P^(m-1)
         uint32_t h1 = 0, h2 = 0;
@@ -381,13 +366,18 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         cursor = 1;
     }
     uint64_t w0 = s0;
+    // software prefetch: `cur` = bytes [w0, w0+64), `nxt` = bytes [w0+64, w0+128) (0 past the document end).
+    // The next window starts at w0 + region_end <= w0 + 64, so its bytes are a lane rotation of
+    // (cur, nxt); the global load issued for the new `nxt` is only consumed one window later.
+    uint32_t cur = (w0 + (uint64_t)lane < s1) ? (uint32_t)a.bytes[w0 + lane] : 0u;
+    uint32_t nxt = (w0 + 64 + (uint64_t)lane < s1) ? (uint32_t)a.bytes[w0 + 64 + lane] : 0u;
     while (w0 < s1) {
         const uint64_t rem = s1 - w0;
         int nv = rem < 64 ? (int)rem : 64;
         const bool at_end = rem <= 64;
 
         // ---- 1. load + classify ---------------------------------------------------------
-        uint32_t b0 = lane < nv ? (uint32_t)a.bytes[w0 + lane] : 0u;
+        uint32_t b0 = lane < nv ? cur : 0u;
         if (!at_end) {
             // a char cut by the window end has an unknown class: leave it to the next window
             uint32_t nominal = b0 < 0xC0u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : b0 < 0xF8u ? 4u : 1u;
@@ -517,12 +507,22 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
                 const uint64_t e = wv_first64(tk_match_end(t, a.bytes, w0, s1));
                 for (uint64_t q = w0 + (uint64_t)lane; q < e; q += 64) a.dbg_starts[q] = (q == w0);
                 w0 = e;
+                cur = (w0 + (uint64_t)lane < s1) ? (uint32_t)a.bytes[w0 + lane] : 0u;
+                nxt = (w0 + 64 + (uint64_t)lane < s1) ? (uint32_t)a.bytes[w0 + 64 + lane] : 0u;
                 continue;
             }
             region_end = estar;
             PSp = cert & ~(1ull << estar);
         }
         const bool inreg = lane < region_end;
+        // slide: rotate (cur, nxt) by region_end lanes and start the load of the following 64 bytes
+        {
+            const int idx = region_end + lane;
+            const uint32_t ra = wv_shfl(cur, idx & 63), rb = wv_shfl(nxt, idx & 63);
+            const uint64_t nw = w0 + (uint64_t)region_end;
+            cur = idx < 64 ? ra : rb;
+            nxt = (nw + 64 + (uint64_t)lane < s1) ? (uint32_t)a.bytes[nw + 64 + lane] : 0u;
+        }
         if (MODE == 2) {
             if (inreg) a.dbg_starts[w0 + lane] = tk_bit(PSp, lane);
             w0 += (uint64_t)region_end;
@@ -568,16 +568,17 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         if (isstart) {
             if (len == 1) {
                 tokv = b0;  // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
-            } else if (len <= 8) {
-                uint32_t lo = d4, hi = d4hi;
-                if (len <= 4) { hi = 0u; if (len < 4) lo &= (1u << (8 * len)) - 1u; }
-                else if (len < 8) hi &= (1u << (8 * (len - 4))) - 1u;
-                tokv = tk_probe_short(t, lo, hi, (uint32_t)len);
             } else if (len <= 16) {
-                uint32_t k1 = d4hi, k2 = d4b, k3 = d4c;
-                if (len <= 12) { k3 = 0u; if (len < 12) k2 &= (1u << (8 * (len - 8))) - 1u; }
-                else if (len < 16) k3 &= (1u << (8 * (len - 12))) - 1u;
-                tokv = tk_probe_mid(t, d4, k1, k2, k3, (uint32_t)len);
+                // exact key: the piece bytes themselves, zero padded to 16
+                const uint32_t keep = 8u * (uint32_t)(len & 3);
+                const uint32_t part = keep ? ((1u << keep) - 1u) : 0xFFFFFFFFu;  // mask of the last, partial dword
+                const int nd = (len + 3) >> 2;                                       // dwords that carry bytes
+                uint32_t k0 = d4, k1 = d4hi, k2 = d4b, k3 = d4c;
+                k0 &= nd == 1 ? part : 0xFFFFFFFFu;
+                k1 &= nd < 2 ? 0u : nd == 2 ? part : 0xFFFFFFFFu;
+                k2 &= nd < 3 ? 0u : nd == 3 ? part : 0xFFFFFFFFu;
+                k3 &= nd < 4 ? 0u : part;
+                tokv = tk_probe_key(t, k0, k1, k2, k3, (uint32_t)len);
             } else {
                 tokv = tk_probe_long(t, h1, h2, (uint32_t)len, a.bytes + w0 + lane);
             }

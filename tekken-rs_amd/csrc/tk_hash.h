@@ -4,13 +4,12 @@
 // Three lookup structures replace the FxHashMap<Vec<u8>,u32> that the reference hands to
 // CoreBPE::new (reference src/tekkenizer.rs:118-126, built at :776-816):
 //
-//   SHORT  piece bytes (2..8 bytes, exact 64-bit key + length)          -> rank
-//   MID    piece bytes (9..16 bytes, exact 128-bit key + length)        -> rank
+//   KEY    piece bytes (2..16 bytes, exact 128-bit key + length)        -> rank
 //   LONG   piece bytes (>= 17 bytes, polynomial hash, verified vs blob)  -> rank
 //   PAIR   (id(A), id(B))  ->  rank(bytes(A) ++ bytes(B))                
 //   PAIR2  direct 64K table for two single bytes                         -> rank
 //
-// SHORT/MID/LONG serve the whole-piece shortcut, PAIR/PAIR2 serve the merge loop.
+// KEY/LONG serve the whole-piece shortcut, PAIR/PAIR2 serve the merge loop.
 #ifndef TK_HASH_H
 #define TK_HASH_H
 #include <stdint.h>
@@ -29,16 +28,10 @@
 #define TK_POLY_P1 0x01000193u           /* odd => invertible mod 2^32 */
 #define TK_POLY_P2 0x9E3779B1u
 
-struct alignas(16) tk_short_entry {      /* 16 B, len == 0 <=> empty */
-    uint32_t key_lo, key_hi;             /* piece bytes little-endian, zero padded */
-    uint32_t rank;
-    uint32_t len;                        /* 2..8 */
-};
-
-struct alignas(32) tk_mid_entry {        /* 32 B, len == 0 <=> empty: pieces of 9..16 bytes, exact 128-bit key */
+struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 2..16 bytes, exact 128-bit key */
     uint32_t k[4];                       /* piece bytes little-endian, zero padded */
     uint32_t rank;
-    uint32_t len;                        /* 9..16 */
+    uint32_t len;                        /* 2..16 */
     uint32_t pad[2];
 };
 
@@ -54,11 +47,7 @@ TK_HD uint32_t tk_fmix32(uint32_t h) {
     return h;
 }
 
-TK_HD uint32_t tk_short_hash(uint32_t lo, uint32_t hi, uint32_t len) {
-    return tk_fmix32(lo * 0x9E3779B1u + (hi ^ (len << 28)) * 0x85EBCA77u + len);
-}
-
-TK_HD uint32_t tk_mid_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+TK_HD uint32_t tk_key_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
     uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du + k3 * 0x27D4EB2Fu + len * 0x165667B1u;
     return tk_fmix32(h);
 }

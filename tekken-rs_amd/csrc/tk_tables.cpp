@@ -27,14 +27,12 @@ TkTablesView TkHostTables::host_view() const {
     TkTablesView v;
     v.uc_stage1 = uc_stage1.data();
     v.uc_stage2 = uc_stage2.data();
-    v.short_tab = short_tab.data();
-    v.mid_tab = mid_tab.data();
+    v.key_tab = key_tab.data();
     v.long_tab = long_tab.data();
     v.pair_tab = pair_tab.data();
     v.pair2 = pair2.data();
     v.blob = blob.data();
-    v.short_mask = short_mask;
-    v.mid_mask = mid_mask;
+    v.key_mask = key_mask;
     v.long_mask = long_mask;
     v.pair_mask = pair_mask;
     v.n_ranks = n_ranks;
@@ -97,22 +95,18 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         }
     }
 
-    uint64_t n_short = 0, n_mid = 0, n_long = 0;
+    uint64_t n_key = 0, n_long = 0;
     for (uint32_t r = 0; r < n_ranks; ++r) {
         uint32_t len = offs[r + 1] - offs[r];
-        if (len >= 2 && len <= 8) ++n_short;
-        else if (len >= 9 && len <= 16) ++n_mid;
+        if (len >= 2 && len <= 16) ++n_key;
         else if (len >= 17) ++n_long;
     }
-    out.n_short = n_short;
-    out.n_mid = n_mid;
+    out.n_key = n_key;
     out.n_long = n_long;
-    uint32_t scap = pow2_at_least(2 * n_short + 1), mcap = pow2_at_least(2 * n_mid + 1), lcap = pow2_at_least(2 * n_long + 1);
-    out.short_mask = scap - 1;
-    out.mid_mask = mcap - 1;
+    uint32_t kcap = pow2_at_least(2 * n_key + 1), lcap = pow2_at_least(2 * n_long + 1);
+    out.key_mask = kcap - 1;
     out.long_mask = lcap - 1;
-    out.short_tab.assign(scap, tk_short_entry{0, 0, 0, 0});
-    out.mid_tab.assign(mcap, tk_mid_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
+    out.key_tab.assign(kcap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
     out.long_tab.assign(lcap, tk_long_entry{0, 0, 0, 0});
     out.pair2.assign(65536, TK_RANK_MAX);
 
@@ -120,20 +114,13 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         const uint8_t* p = blob + offs[r];
         uint32_t len = offs[r + 1] - offs[r];
         if (len == 2) out.pair2[p[0] | ((uint32_t)p[1] << 8)] = r;
-        if (len >= 2 && len <= 8) {
-            uint64_t key = 0;
-            for (uint32_t k = 0; k < len; ++k) key |= (uint64_t)p[k] << (8 * k);
-            uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-            uint32_t s = tk_short_hash(lo, hi, len) & out.short_mask;
-            while (out.short_tab[s].len) s = (s + 1) & out.short_mask;
-            out.short_tab[s] = tk_short_entry{lo, hi, r, len};
-        } else if (len <= 16) {
+        if (len >= 2 && len <= 16) {
             uint32_t k[4] = {0, 0, 0, 0};
             for (uint32_t j = 0; j < len; ++j) k[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
-            uint32_t s = tk_mid_hash(k[0], k[1], k[2], k[3], len) & out.mid_mask;
-            while (out.mid_tab[s].len) s = (s + 1) & out.mid_mask;
-            out.mid_tab[s] = tk_mid_entry{{k[0], k[1], k[2], k[3]}, r, len, {0, 0}};
-        } else {
+            uint32_t s = tk_key_hash(k[0], k[1], k[2], k[3], len) & out.key_mask;
+            while (out.key_tab[s].len) s = (s + 1) & out.key_mask;
+            out.key_tab[s] = tk_key_entry{{k[0], k[1], k[2], k[3]}, r, len, {0, 0}};
+        } else if (len >= 17) {
             uint32_t h1 = 0, h2 = 0;
             for (uint32_t k = 0; k < len; ++k) {
                 h1 = h1 * TK_POLY_P1 + p[k];

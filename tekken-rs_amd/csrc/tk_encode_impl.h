@@ -24,7 +24,7 @@
 // and, on a miss, a wave-cooperative merge over scratch memory with per-64-part block minima.
 //
 // The file is included with a set of wave primitives already defined (wv_lane, wv_ballot,
-// wv_shfl, wv_first, wv_first64, wv_up1, wv_dn1, wv_sync, wv_atomic_add, wv_atomic_add_all, TK_DEV): tk_wave_hip.h for gfx950, and a
+// wv_shfl, wv_first, wv_first64, wv_up1, wv_dn1, wv_sync, wv_atomic_add, wv_atomic_add_all, wv_brev64, TK_DEV): tk_wave_hip.h for gfx950, and a
 // fiber emulator in tests/emu/ that lets the CPU test-suite run this very source.
 #ifndef TK_ENCODE_IMPL_H
 #define TK_ENCODE_IMPL_H
@@ -378,7 +378,8 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
 
         // ---- 1. load + classify ---------------------------------------------------------
         uint32_t b0 = lane < nv ? cur : 0u;
-        if (!at_end) {
+        const bool ascii = wv_ballot(b0 >= 0x80u) == 0;  // wave-uniform: the common case takes the scalar rules
+        if (!at_end && !ascii) {
             // a char cut by the window end has an unknown class: leave it to the next window
             uint32_t nominal = b0 < 0xC0u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : b0 < 0xF8u ? 4u : 1u;
             uint64_t csraw = wv_ballot(lane < nv && ((b0 & 0xC0u) != 0x80u || lane == 0));
@@ -389,107 +390,176 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         }
         const bool valid = lane < nv;
         const uint32_t b1 = wv_up1(b0), b2 = wv_up1(b1), b3 = wv_up1(b2);
-        const bool lead = (b0 & 0xC0u) != 0x80u || lane == 0;
-        uint32_t cls = TK_CLS_O, clen = 1;
-        if (b0 < 0x80u) {
-            cls = tk_ascii_class(b0);
-        } else if (lead && b0 >= 0xC0u) {
-            uint32_t cp = 0xFFFFFFFFu;
-            if (b0 < 0xE0u) {
-                if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
-            } else if (b0 < 0xF0u) {
-                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
-                    cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
-                }
-            } else if (b0 < 0xF8u) {
-                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
-                    cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
+        uint64_t PS;  // piece starts decided by this window
+        int fu;       // first position whose decision unseen bytes could change
+        if (ascii) {
+            // ---- 2a. ASCII window: one byte = one char, the rules are pure 64-bit mask algebra on
+            //          SGPR pairs (no per-lane work, no divergent branch).  Same rules as 2b below.
+            const uint32_t cls = tk_ascii_class(b0);
+            const uint64_t VAL = tk_lowmask(nv);
+            const uint64_t mL = wv_ballot(valid && cls == TK_CLS_L);
+            const uint64_t mN = wv_ballot(valid && cls == TK_CLS_N);
+            const uint64_t mS = wv_ballot(valid && cls == TK_CLS_S);
+            const uint64_t mO = VAL & ~(mL | mN | mS);
+            const uint64_t NLm = wv_ballot(valid && (b0 == 10u || b0 == 13u));
+            const uint64_t SPm = wv_ballot(valid && b0 == 0x20u);
+            const uint64_t APm = wv_ballot(valid && b0 == 0x27u);
+            uint64_t CEND = 0;
+            if (APm) {  // alt 1 fires only where a match starts at the apostrophe
+                const uint32_t f1 = b1 | 0x20u, f2 = b2 | 0x20u;
+                const bool c2 = f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd';
+                const bool c3 = ((f1 == 'r' || f1 == 'v') && f2 == 'e') || (f1 == 'l' && f2 == 'l');
+                const uint64_t ok = APm & ~((mO | SPm) << 1);
+                CEND = ((wv_ballot(c2) & ok) << 2) | ((wv_ballot(c3 && !c2) & ok) << 3);
+            }
+            const uint64_t L1 = mL << 1, O1 = mO << 1;
+            const uint64_t Lst = mL & ~L1;
+            const uint64_t psL = (mL & L1 & CEND) | (Lst & ((mN | NLm) << 1)) | (Lst & O1 & ((mO | SPm) << 2));
+            const uint64_t psO = mO & ~O1 & ~(SPm << 1);
+            uint64_t psN = mN & ~(mN << 1);
+            {
+                const uint64_t M3 = mN & (mN << 1) & (mN << 2) & (mN << 3);  // q-3..q all numbers
+                if (M3) {  // a run of >= 4 numbers: starts every 3 chars (\p{N}{1,3}), by prefix doubling
+                    const uint64_t M6 = M3 & (M3 << 3), M12 = M6 & (M6 << 6), M24 = M12 & (M12 << 12);
+                    const uint64_t M48 = M24 & (M24 << 24);
+                    psN |= (psN << 3) & M3;
+                    psN |= (psN << 6) & M6;
+                    psN |= (psN << 12) & M12;
+                    psN |= (psN << 24) & M24;
+                    psN |= (psN << 48) & M48;
                 }
             }
-            if (cp != 0xFFFFFFFFu) cls = tk_uc_class(t, cp);
-        }
-        const uint64_t CS = wv_ballot(valid && lead);
-        {
-            // continuation bytes take the class of their lead byte so that runs are contiguous
-            const uint32_t c1 = wv_dn1(cls), c2 = wv_dn1(c1), c3 = wv_dn1(c2);
-            if (!lead) {
-                int dist = lane - tk_msb64(CS & tk_lowmask(lane));
-                cls = dist == 1 ? c1 : dist == 2 ? c2 : dist == 3 ? c3 : TK_CLS_O;
+            // white space: CR/LF absorbed by alt 4 directly after an O run (carry ripple)
+            const uint64_t seeds = NLm & O1;
+            const uint64_t ABS = seeds ? (((NLm + seeds) ^ NLm) & NLm) : 0ull;
+            const uint64_t SPR = mS & ~ABS;
+            const uint64_t NLp = NLm & SPR;
+            uint64_t Z = 0;  // positions up to and including the last CR/LF of their run (\s*[\r\n]+)
+            if (NLp) {
+                // T = the part of each run above its last CR/LF, found in bit-reversed space by a
+                // ripple from the run tops through the non-CR/LF bits
+                const uint64_t r = wv_brev64(SPR), s = wv_brev64(NLp);
+                const uint64_t u = r & ~s;
+                const uint64_t tops = r & ~(r << 1) & u;
+                const uint64_t T = wv_brev64(((u + tops) ^ u) & u);
+                Z = SPR & ~T;
             }
-        }
-        const uint64_t mL = wv_ballot(valid && cls == TK_CLS_L);
-        const uint64_t mN = wv_ballot(valid && cls == TK_CLS_N);
-        const uint64_t mS = wv_ballot(valid && cls == TK_CLS_S);
-        const uint64_t mO = wv_ballot(valid && cls == TK_CLS_O);
-        const uint64_t NLm = wv_ballot(valid && (b0 == 10u || b0 == 13u));
-        const uint64_t SPm = wv_ballot(valid && b0 == 0x20u);
-
-        // ---- 2. local piece-start rules ---------------------------------------------------
-        // alt 1 (?i:'s|'t|'re|'ve|'m|'ll|'d): fires only where a match starts at the apostrophe
-        uint32_t ce = 0;
-        if (b0 == 0x27u) {
-            const uint32_t f1 = b1 | 0x20u, f2 = b2 | 0x20u;
-            if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') ce = 2;
-            else if (b1 == 0xC5u && b2 == 0xBFu) ce = 3;  // U+017F folds to 's'
-            else if (((f1 == 'r' || f1 == 'v') && f2 == 'e') || (f1 == 'l' && f2 == 'l')) ce = 3;
-        }
-        const bool fire = ce && (lane == 0 || (!tk_bit(mO, lane - 1) && !tk_bit(SPm, lane - 1)));
-        const uint64_t F2 = wv_ballot(valid && fire && ce == 2);
-        const uint64_t F3 = wv_ballot(valid && fire && ce == 3);
-        const uint64_t CEND = (F2 << 2) | (F3 << 3);
-        // CR/LF absorbed by alt 4's trailing [\r\n]*: leading CR/LF of a white-space run that
-        // directly follows a class-O byte (carry ripple through the CR/LF run)
-        const uint64_t seeds = NLm & (mO << 1);
-        const uint64_t ABS = ((NLm + seeds) ^ NLm) & NLm;
-        const uint64_t SPR = mS & ~ABS;  // effective white space
-        const uint64_t Nst = mN & ~(mN << 1);
-
-        bool st = false, unc = false;
-        if (valid && lead) {
-            if (lane == 0) {
-                st = true;
-            } else {
-                const int pm = lane - 1;
-                const bool pL = tk_bit(mL, pm), pN = tk_bit(mN, pm), pS = tk_bit(mS, pm), pO = tk_bit(mO, pm);
-                if (cls == TK_CLS_L) {
-                    if (pL) st = tk_bit(CEND, lane);             // only right after a contraction
-                    else if (pN) st = true;
-                    else if (pS) st = tk_bit(NLm, pm);           // other white space is alt 2's prefix
-                    else {
-                        const int qs = tk_msb64(CS & tk_lowmask(lane));
-                        const bool runstart = qs == 0 || !tk_bit(mO, qs - 1);
-                        st = !runstart || (qs > 0 && tk_bit(SPm, qs - 1));
+            const uint64_t psS = (SPR & ~(SPR << 1)) | ((Z << 1) & SPR & ~Z) | (SPR & ~(SPR >> 1) & ~Z & (VAL >> 1));
+            PS = (psL | psN | psO | psS | 1ull) & VAL;
+            fu = nv;
+            if (!at_end && tk_bit(SPR, nv - 1)) {  // the run that touches the window end is undecided past its first char
+                const uint64_t below = ~SPR & VAL;
+                const int rs = below ? tk_msb64(below) + 1 : 0;
+                fu = rs + 1 < nv ? rs + 1 : nv;
+            }
+        } else {
+            // ---- 2b. general window (multi-byte code points): per-lane rules
+            const bool lead = (b0 & 0xC0u) != 0x80u || lane == 0;
+            uint32_t cls = TK_CLS_O, clen = 1;
+            if (b0 < 0x80u) {
+                cls = tk_ascii_class(b0);
+            } else if (lead && b0 >= 0xC0u) {
+                uint32_t cp = 0xFFFFFFFFu;
+                if (b0 < 0xE0u) {
+                    if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
+                } else if (b0 < 0xF0u) {
+                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
+                        cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
                     }
-                } else if (cls == TK_CLS_N) {
-                    if (!pN) st = true;
-                    else {
-                        const int rs = tk_msb64(Nst & tk_lowmask(lane + 1));
-                        const int k = tk_popc64(CS & tk_lowmask(lane) & ~tk_lowmask(rs));
-                        st = (k % 3) == 0;                       // \p{N}{1,3}
+                } else if (b0 < 0xF8u) {
+                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
+                        cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
                     }
-                } else if (cls == TK_CLS_O) {
-                    st = !pO && !tk_bit(SPm, pm);                // ' ?' of alt 4 takes one U+0020
+                }
+                if (cp != 0xFFFFFFFFu) cls = tk_uc_class(t, cp);
+            }
+            const uint64_t CS = wv_ballot(valid && lead);
+            {
+                // continuation bytes take the class of their lead byte so that runs are contiguous
+                const uint32_t c1 = wv_dn1(cls), c2 = wv_dn1(c1), c3 = wv_dn1(c2);
+                if (!lead) {
+                    int dist = lane - tk_msb64(CS & tk_lowmask(lane));
+                    cls = dist == 1 ? c1 : dist == 2 ? c2 : dist == 3 ? c3 : TK_CLS_O;
+                }
+            }
+            const uint64_t mL = wv_ballot(valid && cls == TK_CLS_L);
+            const uint64_t mN = wv_ballot(valid && cls == TK_CLS_N);
+            const uint64_t mS = wv_ballot(valid && cls == TK_CLS_S);
+            const uint64_t mO = wv_ballot(valid && cls == TK_CLS_O);
+            const uint64_t NLm = wv_ballot(valid && (b0 == 10u || b0 == 13u));
+            const uint64_t SPm = wv_ballot(valid && b0 == 0x20u);
+
+            // (local piece-start rules, per lane) ---------------------------------------------------
+            // alt 1 (?i:'s|'t|'re|'ve|'m|'ll|'d): fires only where a match starts at the apostrophe
+            uint32_t ce = 0;
+            if (b0 == 0x27u) {
+                const uint32_t f1 = b1 | 0x20u, f2 = b2 | 0x20u;
+                if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') ce = 2;
+                else if (b1 == 0xC5u && b2 == 0xBFu) ce = 3;  // U+017F folds to 's'
+                else if (((f1 == 'r' || f1 == 'v') && f2 == 'e') || (f1 == 'l' && f2 == 'l')) ce = 3;
+            }
+            const bool fire = ce && (lane == 0 || (!tk_bit(mO, lane - 1) && !tk_bit(SPm, lane - 1)));
+            const uint64_t F2 = wv_ballot(valid && fire && ce == 2);
+            const uint64_t F3 = wv_ballot(valid && fire && ce == 3);
+            const uint64_t CEND = (F2 << 2) | (F3 << 3);
+            // CR/LF absorbed by alt 4's trailing [\r\n]*: leading CR/LF of a white-space run that
+            // directly follows a class-O byte (carry ripple through the CR/LF run)
+            const uint64_t seeds = NLm & (mO << 1);
+            const uint64_t ABS = ((NLm + seeds) ^ NLm) & NLm;
+            const uint64_t SPR = mS & ~ABS;  // effective white space
+            const uint64_t Nst = mN & ~(mN << 1);
+
+            bool st = false, unc = false;
+            if (valid && lead) {
+                if (lane == 0) {
+                    st = true;
                 } else {
-                    (void)pS;
-                    if (tk_bit(ABS, lane)) st = false;
-                    else if (!tk_bit(SPR, pm)) st = true;        // start of the effective run
-                    else {
-                        const uint64_t x = SPR >> lane;
-                        const int rl = tk_ctz64(~x);
-                        const int e = lane + rl;
-                        if (!at_end && e >= nv) unc = true;      // run reaches unseen bytes
+                    const int pm = lane - 1;
+                    const bool pL = tk_bit(mL, pm), pN = tk_bit(mN, pm), pS = tk_bit(mS, pm), pO = tk_bit(mO, pm);
+                    if (cls == TK_CLS_L) {
+                        if (pL) st = tk_bit(CEND, lane);             // only right after a contraction
+                        else if (pN) st = true;
+                        else if (pS) st = tk_bit(NLm, pm);           // other white space is alt 2's prefix
                         else {
-                            const bool later_nl = ((NLm >> lane) & tk_lowmask(rl)) != 0;
-                            if (later_nl) st = false;            // inside \s*[\r\n]+
-                            else if (tk_bit(NLm, pm)) st = true; // first char after the last CR/LF
-                            else st = (lane + (int)clen == e) && (e < nv);  // \s+(?!\S) leaves the last char
+                            const int qs = tk_msb64(CS & tk_lowmask(lane));
+                            const bool runstart = qs == 0 || !tk_bit(mO, qs - 1);
+                            st = !runstart || (qs > 0 && tk_bit(SPm, qs - 1));
+                        }
+                    } else if (cls == TK_CLS_N) {
+                        if (!pN) st = true;
+                        else {
+                            const int rs = tk_msb64(Nst & tk_lowmask(lane + 1));
+                            const int k = tk_popc64(CS & tk_lowmask(lane) & ~tk_lowmask(rs));
+                            st = (k % 3) == 0;                       // \p{N}{1,3}
+                        }
+                    } else if (cls == TK_CLS_O) {
+                        st = !pO && !tk_bit(SPm, pm);                // ' ?' of alt 4 takes one U+0020
+                    } else {
+                        (void)pS;
+                        if (tk_bit(ABS, lane)) st = false;
+                        else if (!tk_bit(SPR, pm)) st = true;        // start of the effective run
+                        else {
+                            const uint64_t x = SPR >> lane;
+                            const int rl = tk_ctz64(~x);
+                            const int e = lane + rl;
+                            if (!at_end && e >= nv) unc = true;      // run reaches unseen bytes
+                            else {
+                                const bool later_nl = ((NLm >> lane) & tk_lowmask(rl)) != 0;
+                                if (later_nl) st = false;            // inside \s*[\r\n]+
+                                else if (tk_bit(NLm, pm)) st = true; // first char after the last CR/LF
+                                else st = (lane + (int)clen == e) && (e < nv);  // \s+(?!\S) leaves the last char
+                            }
                         }
                     }
                 }
             }
+            PS = wv_ballot(st);
+            {
+                const uint64_t UNC = wv_ballot(unc);
+                fu = UNC ? tk_ctz64(UNC) : nv;
+            }
+
         }
-        const uint64_t PS = wv_ballot(st);
-        const uint64_t UNC = wv_ballot(unc);
 
         // ---- 3. how far may this window commit? -------------------------------------------
         int region_end;
@@ -498,7 +568,6 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             region_end = nv;
             PSp = PS;
         } else {
-            const int fu = UNC ? tk_ctz64(UNC) : nv;
             const uint64_t cert = PS & tk_lowmask(fu);
             const int estar = tk_msb64(cert);
             if (estar == 0) {

@@ -39,6 +39,8 @@ TK_DEV void wv_sync() {
 }
 
 // executed by ONE lane (inside a lane-predicated block whose result feeds no wave primitive)
+TK_DEV uint64_t wv_brev64(uint64_t x) { return __builtin_bitreverse64(x); }  // s_brev_b64 on uniform values
+
 TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
 // executed by ALL 64 lanes in uniform control flow: *p += 64*v, lane i receives old + i*v

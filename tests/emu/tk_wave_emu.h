@@ -159,6 +159,12 @@ TK_DEV uint32_t wv_dn1(uint32_t v) {
     return lane > 0 ? tkemu::g_wave->snap_u32[lane - 1] : 0u;
 }
 
+TK_DEV uint64_t wv_brev64(uint64_t x) {
+    uint64_t r = 0;
+    for (int i = 0; i < 64; ++i) r |= ((x >> i) & 1ull) << (63 - i);
+    return r;
+}
+
 TK_DEV void wv_sync() { tkemu::yield_op(tkemu::OP_SYNC); }
 
 TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) {

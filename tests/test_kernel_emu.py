@@ -37,3 +37,35 @@ def test_emu_reference_vectors_on_consistent_vocab(golden):
     got, _, _ = emu.encode_batch(toks, 1000, 1, 2, [t.encode("utf-8") for t in texts], False, False)
     for (t, ids), g in zip(golden["ref"]["encode"], got):
         assert g == ids, t
+
+
+def test_emu_split_exhaustive_ascii(small_vocab):
+    """Every string of length <= 5 over an 8-symbol ASCII alphabet through the device split (the
+    scalar mask-algebra path of ASCII windows), against the oracle."""
+    import itertools
+    import tk_oracle
+    alpha = ["a", "s", "1", "'", "!", " ", "\n", "\t"]
+    docs = ["".join(t).encode() for n in range(0, 6) for t in itertools.product(alpha, repeat=n)]
+    _, starts, _ = emu.encode_batch(small_vocab["tokens"], 10, 1, 2, docs, split_only=True)
+    for d, s in zip(docs, starts):
+        assert s == tk_oracle.split(d), d
+
+
+def test_emu_split_long_ascii_windows(small_vocab):
+    """Multi-window ASCII documents: digit runs (prefix doubling), long white-space runs with CR/LF,
+    runs crossing window boundaries."""
+    import random
+    import tk_oracle
+    rng = random.Random(21)
+    alpha = ["a", "b", "1", "2", "'", "s", "t", "!", "-", " ", " ", " ", "\n", "\r", "\t"]
+    docs = []
+    for _ in range(400):
+        n = rng.randint(60, 400)
+        parts = []
+        while sum(map(len, parts)) < n:
+            c = rng.choice(alpha)
+            parts.append(c * rng.choice([1, 1, 1, 2, 3, 5, 9, 17, 40]))
+        docs.append("".join(parts).encode())
+    _, starts, _ = emu.encode_batch(small_vocab["tokens"], 10, 1, 2, docs, split_only=True)
+    for d, s in zip(docs, starts):
+        assert s == tk_oracle.split(d), d

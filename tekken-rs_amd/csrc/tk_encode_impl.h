@@ -68,13 +68,17 @@ TK_DEV uint32_t tk_uc_class(const TkTablesView& t, uint32_t cp) {
     return (w >> (2u * (cp & 15u))) & 3u;
 }
 
+struct alignas(16) tk_u32x4 { uint32_t x, y, z, w; };
+
+// One probe = ONE round trip: the 32-byte entry is fetched with two 16-byte loads issued together and
+// compared with bitwise ops (a short-circuit && chain compiles to one dependent load per field).
 TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
     uint32_t s = tk_key_hash(k0, k1, k2, k3, len) & t.key_mask;
-    for (uint32_t tries = 0; tries <= t.key_mask; ++tries) {
-        const tk_key_entry* e = t.key_tab + s;
-        const uint32_t el = e->len;
-        if (el == 0u) return TK_RANK_MAX;
-        if (el == len && e->k[0] == k0 && e->k[1] == k1 && e->k[2] == k2 && e->k[3] == k3) return e->rank;
+    for (uint32_t tries = 0; tries <= t.key_mask; ++tries) {  // load factor <= 1/2: an empty slot is always met
+        const tk_u32x4* e = reinterpret_cast<const tk_u32x4*>(t.key_tab + s);
+        const tk_u32x4 a = e[0], b = e[1];  // a = key, b = {rank, len, pad, pad}
+        if (b.y == 0u) return TK_RANK_MAX;
+        if (((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u) return b.x;
         s = (s + 1u) & t.key_mask;
     }
     return TK_RANK_MAX;
@@ -85,13 +89,13 @@ TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, ui
 TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, uint32_t len, const uint8_t* text) {
     uint32_t s = tk_long_hash(h1, len) & t.long_mask;
     for (uint32_t tries = 0; tries <= t.long_mask; ++tries) {
-        tk_long_entry e = t.long_tab[s];
-        if (e.len == 0u) return TK_RANK_MAX;
-        if (e.len == len && e.tag == h2) {
-            const uint8_t* q = t.blob + e.blob_off;
-            uint32_t k = 0;
-            while (k < len && q[k] == text[k]) ++k;
-            if (k == len) return e.rank;
+        const tk_u32x4 e = *reinterpret_cast<const tk_u32x4*>(t.long_tab + s);  // {tag, rank, len, blob_off}
+        if (e.z == 0u) return TK_RANK_MAX;
+        if (((e.z ^ len) | (e.x ^ h2)) == 0u) {
+            const uint8_t* q = t.blob + e.w;
+            uint32_t diff = 0;
+            for (uint32_t k = 0; k < len; ++k) diff |= (uint32_t)(q[k] ^ text[k]);  // no early exit: loads pipeline
+            if (diff == 0u) return e.y;
         }
         s = (s + 1u) & t.long_mask;
     }
@@ -397,13 +401,14 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
             //          SGPR pairs (no per-lane work, no divergent branch).  Same rules as 2b below.
             const uint32_t cls = tk_ascii_class(b0);
             const uint64_t VAL = tk_lowmask(nv);
-            const uint64_t mL = wv_ballot(valid && cls == TK_CLS_L);
-            const uint64_t mN = wv_ballot(valid && cls == TK_CLS_N);
-            const uint64_t mS = wv_ballot(valid && cls == TK_CLS_S);
+            // bytes past nv are 0 (class O), so single compares are already masked by validity
+            const uint64_t mL = wv_ballot(cls == TK_CLS_L);
+            const uint64_t mN = wv_ballot(cls == TK_CLS_N);
+            const uint64_t mS = wv_ballot(cls == TK_CLS_S);
             const uint64_t mO = VAL & ~(mL | mN | mS);
-            const uint64_t NLm = wv_ballot(valid && (b0 == 10u || b0 == 13u));
-            const uint64_t SPm = wv_ballot(valid && b0 == 0x20u);
-            const uint64_t APm = wv_ballot(valid && b0 == 0x27u);
+            const uint64_t NLm = wv_ballot(b0 == 10u) | wv_ballot(b0 == 13u);
+            const uint64_t SPm = wv_ballot(b0 == 0x20u);
+            const uint64_t APm = wv_ballot(b0 == 0x27u);
             uint64_t CEND = 0;
             if (APm) {  // alt 1 fires only where a match starts at the apostrophe
                 const uint32_t f1 = b1 | 0x20u, f2 = b2 | 0x20u;

@@ -8,7 +8,7 @@
 
 TK_DEV int wv_lane() { return (int)(threadIdx.x & 63u); }
 
-TK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
+TK_DEV uint64_t wv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the compare mask itself, no VGPR round trip
 
 // value of `v` in lane `src` (0..63); every lane of the wave must execute it
 TK_DEV uint32_t wv_shfl(uint32_t v, int src) {

@@ -77,8 +77,10 @@ TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, ui
     for (uint32_t tries = 0; tries <= t.key_mask; ++tries) {  // load factor <= 1/2: an empty slot is always met
         const tk_u32x4* e = reinterpret_cast<const tk_u32x4*>(t.key_tab + s);
         const tk_u32x4 a = e[0], b = e[1];  // a = key, b = {rank, len, pad, pad}
-        if (b.y == 0u) return TK_RANK_MAX;
-        if (((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u) return b.x;
+        const uint32_t diff = (a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len);
+        // one exit test on BOTH loads (an early `if (len == 0)` makes the compiler sink the key load behind it)
+        const uint32_t res = diff == 0u ? b.x : TK_RANK_MAX;
+        if ((res != TK_RANK_MAX) | (b.y == 0u)) return res;  // ranks are < 2^21, so MAX is never a rank
         s = (s + 1u) & t.key_mask;
     }
     return TK_RANK_MAX;

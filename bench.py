@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=2, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = dry run of the N>1 code path with several ranks sharing one GPU (ids staged through host)")
     args = ap.parse_args()
 
     import torch
@@ -61,10 +63,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and not distributed:
         raise SystemExit("for --gpus > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    xdev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the collectives' tensors live
 
     # ---- vocabulary (real tekken.json if TEKKEN_JSON is set, else the seeded synthetic one) ----
     vocab_path = args.vocab or sv.ensure_default()
@@ -96,7 +103,7 @@ def main():
         if distributed:
             ids = torch.as_tensor(v_ids, device="cuda")
             oo = torch.as_tensor(v_oo, device="cuda")
-            gathered = par.gather_ids(ids, oo[1:] - oo[:-1], dst=0)
+            gathered = par.gather_ids(ids.to(xdev), (oo[1:] - oo[:-1]).to(xdev), dst=0)
         return v_ids, v_oo
 
     for _ in range(args.warmup):
@@ -115,15 +122,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([n_bytes, n_ids_local], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([n_bytes, n_ids_local], dtype=torch.int64, device=xdev)
         dist.all_reduce(tot)
         total_bytes, total_ids = int(tot[0].item()), int(tot[1].item())
     else:
         total_bytes, total_ids = n_bytes, n_ids_local
 
+    if rank == 0 and distributed:
+        g_ids, g_offs = gathered
+        assert g_ids.numel() == total_ids and g_offs.numel() == args.docs * world + 1 and int(g_offs[-1]) == total_ids
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_bytes / 1e6 / (elapsed / args.steps)

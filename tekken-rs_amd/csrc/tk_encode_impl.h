@@ -116,6 +116,25 @@ TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
     return TK_RANK_MAX;
 }
 
+// two independent PAIR probes whose first-slot loads are issued together (one round trip for both)
+TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t& r0,
+                             uint32_t& r1) {
+    const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
+    uint32_t s0 = tk_pair_hash(a0, b0) & t.pair_mask, s1 = tk_pair_hash(a1, b1) & t.pair_mask;
+    uint64_t e0 = t.pair_tab[s0], e1 = t.pair_tab[s1];
+    r0 = TK_RANK_MAX;
+    r1 = TK_RANK_MAX;
+    for (uint32_t tries = 0; tries <= t.pair_mask; ++tries) {
+        const bool done0 = (e0 == TK_PAIR_EMPTY) | (tk_pair_key(e0) == key0);
+        const bool done1 = (e1 == TK_PAIR_EMPTY) | (tk_pair_key(e1) == key1);
+        if (done0 & done1) break;
+        if (!done0) { s0 = (s0 + 1u) & t.pair_mask; e0 = t.pair_tab[s0]; }
+        if (!done1) { s1 = (s1 + 1u) & t.pair_mask; e1 = t.pair_tab[s1]; }
+    }
+    if (e0 != TK_PAIR_EMPTY && tk_pair_key(e0) == key0) r0 = tk_pair_rank(e0);
+    if (e1 != TK_PAIR_EMPTY && tk_pair_key(e1) == key1) r1 = tk_pair_rank(e1);
+}
+
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {
     for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, lane ^ d);
     return v;
@@ -280,75 +299,89 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         return;
     }
 
-    // ---- wave-cooperative merge over scratch: tok | prk | nxt | prv | bmin(u64) ----
+    // ---- wave-cooperative merge over scratch: node[nn] = {tok, prk, nxt, prv} (16 B) | bmin[nb] (u64) ----
+    // prk = rank of the pair (this part, next part); bmin[b] = min over the 64 nodes of block b of
+    // (prk << 32 | position), so the global leftmost minimum is the min over bmin.  Per merge: one read
+    // of bmin, node i, nodes j and p together, node k, both re-probes together, one store batch, and a
+    // refresh of at most 3 block minima that patches the just-written ranks in registers (no wait on
+    // the stores): about 5 dependent round trips.
     const uint32_t nn = (uint32_t)n;
-    if (a.dbg_mark && lane == 0) { a.dbg_mark[0] = 1u; a.dbg_mark[1] = nn; }
     const uint32_t nb = (nn + 63u) / 64u;
-    uint32_t* tok = scratch;
-    uint32_t* prk = tok + nn;
-    uint32_t* nxt = prk + nn;
-    uint32_t* prv = nxt + nn;
-    uint32_t* bmin = prv + nn;  // 2 words per block: lo = position, hi = rank
+    tk_u32x4* node = reinterpret_cast<tk_u32x4*>(scratch);
+    uint32_t* bmin = scratch + 4u * nn;  // 2 words per block: lo = position, hi = rank
+    if (a.dbg_mark && lane == 0) { a.dbg_mark[0] = 1u; a.dbg_mark[1] = nn; }
     for (uint32_t i = (uint32_t)lane; i < nn; i += 64u) {
-        uint32_t b0 = a.bytes[w0 + i];
-        uint32_t b1 = (i + 1u < nn) ? (uint32_t)a.bytes[w0 + i + 1u] : 0u;
-        tok[i] = b0;
-        prk[i] = (i + 1u < nn) ? t.pair2[b0 | (b1 << 8)] : TK_RANK_MAX;
-        nxt[i] = i + 1u;
-        prv[i] = i ? i - 1u : TK_NONE;
+        const uint32_t b0 = a.bytes[w0 + i];
+        const uint32_t b1 = (i + 1u < nn) ? (uint32_t)a.bytes[w0 + i + 1u] : 0u;
+        tk_u32x4 v;
+        v.x = b0;
+        v.y = (i + 1u < nn) ? t.pair2[b0 | (b1 << 8)] : TK_RANK_MAX;
+        v.z = i + 1u;
+        v.w = i ? i - 1u : TK_NONE;
+        node[i] = v;
     }
     wv_sync();
-    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 2u;
     for (uint32_t blk = 0; blk < nb; ++blk) {
-        uint32_t i = blk * 64u + (uint32_t)lane;
-        uint32_t rk = i < nn ? prk[i] : TK_RANK_MAX;
-        uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | i);
-        uint64_t m = tk_wave_min64(key, lane);
+        const uint32_t x = blk * 64u + (uint32_t)lane;
+        const uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
+        const uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
+        const uint64_t m = tk_wave_min64(key, lane);
         if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
     }
     wv_sync();
-    if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 3u;
     for (uint32_t merges = 0; merges < nn; ++merges) {  // at most nn - 1 merges can happen
         if (a.dbg_mark && lane == 0) a.dbg_mark[2] = merges;
         uint64_t best = ~0ull;
         for (uint32_t bq = (uint32_t)lane; bq < nb; bq += 64u) {
-            uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
+            const uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
             best = v < best ? v : best;
         }
         best = tk_wave_min64(best, lane);
         if (wv_ballot(best != ~0ull) == 0) break;  // decided on a ballot => a scalar branch
         const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
-        const uint32_t j = nxt[i];
-        const uint32_t k = nxt[j];
-        const uint32_t p = prv[i];
-        const uint32_t new_i = (k < nn) ? tk_probe_pair(t, rr, tok[k]) : TK_RANK_MAX;
-        const uint32_t new_p = (p != TK_NONE) ? tk_probe_pair(t, tok[p], rr) : TK_RANK_MAX;
-        wv_sync();
+        const tk_u32x4 Ni = node[i];
+        const uint32_t j = Ni.z, p = Ni.w;
+        const tk_u32x4 Nj = node[j];
+        const tk_u32x4 Np = node[p != TK_NONE ? p : i];
+        const uint32_t k = Nj.z;
+        const uint32_t tok_k = node[k < nn ? k : i].x;
+        uint32_t new_i, new_p;
+        tk_probe_pair_x2(t, rr, tok_k, Np.x, rr, new_i, new_p);
+        if (k >= nn) new_i = TK_RANK_MAX;
+        if (p == TK_NONE) new_p = TK_RANK_MAX;
+        wv_sync();  // every lane has read the nodes before lane 0 rewrites them
         if (lane == 0) {
-            tok[i] = rr; tok[j] = TK_DEAD; prk[j] = TK_RANK_MAX; nxt[i] = k;
-            if (k < nn) prv[k] = i;
-            prk[i] = new_i;
-            if (p != TK_NONE) prk[p] = new_p;
+            tk_u32x4 v;
+            v.x = rr; v.y = new_i; v.z = k; v.w = p;
+            node[i] = v;
+            v.x = TK_DEAD; v.y = TK_RANK_MAX; v.z = Nj.z; v.w = Nj.w;
+            node[j] = v;
+            if (k < nn) node[k].w = i;
+            if (p != TK_NONE) node[p].y = new_p;
         }
-        wv_sync();
-        uint32_t blks[3] = {i / 64u, j / 64u, (p != TK_NONE) ? p / 64u : i / 64u};
-        const bool skip1 = wv_ballot(blks[1] != blks[0]) == 0;
-        const bool skip2 = wv_ballot(blks[2] != blks[0] && blks[2] != blks[1]) == 0;
+        // refresh the block minima of i, j and p; the three just-written ranks are patched in registers
+        const uint32_t bi = i / 64u, bj = j / 64u, bp = (p != TK_NONE) ? p / 64u : bi;
+        const bool skip1 = wv_ballot(bj != bi) == 0;
+        const bool skip2 = wv_ballot(bp != bi && bp != bj) == 0;
         for (int q = 0; q < 3; ++q) {
             if ((q == 1 && skip1) || (q == 2 && skip2)) continue;
-            uint32_t x = blks[q] * 64u + (uint32_t)lane;
-            uint32_t rk = x < nn ? prk[x] : TK_RANK_MAX;
-            uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
-            uint64_t m = tk_wave_min64(key, lane);
-            if (lane == 0) { bmin[2 * blks[q]] = (uint32_t)m; bmin[2 * blks[q] + 1] = (uint32_t)(m >> 32); }
+            const uint32_t blk = q == 0 ? bi : q == 1 ? bj : bp;
+            const uint32_t x = blk * 64u + (uint32_t)lane;
+            uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
+            if (x == i) rk = new_i;
+            if (x == j) rk = TK_RANK_MAX;
+            if (p != TK_NONE && x == p) rk = new_p;
+            const uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
+            const uint64_t m = tk_wave_min64(key, lane);
+            if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
         }
-        wv_sync();
+        wv_sync();  // this merge's stores are visible before the next merge's loads
     }
     if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 5u;
     for (uint32_t blk = 0; blk < nb; ++blk) {
-        uint32_t i = blk * 64u + (uint32_t)lane;
-        uint32_t tv = i < nn ? tok[i] : TK_DEAD;
-        uint64_t am = wv_ballot(tv != TK_DEAD);
+        const uint32_t x = blk * 64u + (uint32_t)lane;
+        const uint32_t tv = x < nn ? node[x].x : TK_DEAD;
+        const uint64_t am = wv_ballot(tv != TK_DEAD);
         if (tv != TK_DEAD) out[cursor + (uint32_t)tk_popc64(am & tk_lowmask(lane))] = tv + t.num_special;
         cursor += (uint32_t)tk_popc64(am);
     }

@@ -58,11 +58,13 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
     ops += tkemu::g_wave->n_ops;
     if (n_deferred) *n_deferred = defer_count;
     if (defer_count) {
-        std::vector<uint32_t> scratch(4 * maxlen + 2 * ((maxlen + 63) / 64) + 64, 0);
+        std::vector<uint32_t> scratch_raw(4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
+        uint32_t* scratch_al = scratch_raw.data();
+        while (reinterpret_cast<uintptr_t>(scratch_al) % 16) ++scratch_al;
         a.todo_list = defer_list.data();
         a.n_todo = defer_count;
-        a.scratch = scratch.data();
-        a.scratch_words_per_wave = scratch.size();
+        a.scratch = scratch_al;
+        a.scratch_words_per_wave = scratch_raw.size() - 8;
         work_counter = 0;
         uint32_t dc2 = 0;
         a.defer_count = &dc2;

@@ -188,6 +188,7 @@ static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_off
     a.add_bos = add_bos;
     a.add_eos = add_eos;
     a.t = c->dview;
+    if (const char* ab = getenv("TK_DEBUG_ABLATE")) a.dbg_ablate = atoi(ab);  // timing-only experiments
     if (getenv("TK_DEBUG_MARKS")) {
         if (!c->dbg_mark) {
             TK_HIP(c, hipHostMalloc((void**)&c->dbg_mark, 256, hipHostMallocMapped));

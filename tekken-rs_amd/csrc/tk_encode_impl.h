@@ -24,7 +24,7 @@
 // and, on a miss, a wave-cooperative merge over scratch memory with per-64-part block minima.
 //
 // The file is included with a set of wave primitives already defined (wv_lane, wv_ballot,
-// wv_shfl, wv_first, wv_first64, wv_up1, wv_dn1, wv_sync, wv_atomic_add, wv_atomic_add_all, wv_brev64, TK_DEV): tk_wave_hip.h for gfx950, and a
+// wv_shfl, wv_first, wv_first64, wv_up1, wv_dn1, wv_sync, wv_atomic_add, wv_atomic_add_all, wv_brev64, wv_min_u32, wv_readlane, TK_DEV): tk_wave_hip.h for gfx950, and a
 // fiber emulator in tests/emu/ that lets the CPU test-suite run this very source.
 #ifndef TK_ENCODE_IMPL_H
 #define TK_ENCODE_IMPL_H
@@ -648,13 +648,12 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         }
         const bool isstart = inreg && tk_bit(PSp, lane);
         const int len = pe - lane;
+        // exact-key material: every lane masks its own 4 bytes to its piece (bytes of the NEXT piece are
+        // zeroed at the source), the start lane then gathers the dwords at +4, +8, +12
         const uint32_t d4 = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        uint32_t d4hi = wv_shfl(d4, lane + 4 < 64 ? lane + 4 : lane);
-        if (lane + 4 >= 64) d4hi = 0u;
-        uint32_t d4b = wv_shfl(d4, lane + 8 < 64 ? lane + 8 : lane);    // bytes 8..11 and 12..15 of the
-        uint32_t d4c = wv_shfl(d4, lane + 12 < 64 ? lane + 12 : lane);  // exact 128-bit key of MID pieces
-        if (lane + 8 >= 64) d4b = 0u;
-        if (lane + 12 >= 64) d4c = 0u;
+        const uint32_t d4m = len >= 4 ? d4 : (d4 & ((1u << (8 * len)) - 1u));  // len = bytes left in my piece (>= 1)
+        const uint32_t g1 = wv_shfl(d4m, (lane + 4) & 63), g2 = wv_shfl(d4m, (lane + 8) & 63);
+        const uint32_t g3 = wv_shfl(d4m, (lane + 12) & 63);
 
         uint32_t h1 = 0, h2 = 0;
         const uint64_t LONGM = wv_ballot(isstart && len >= 17);
@@ -674,19 +673,13 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         }
 
         uint32_t tokv = TK_RANK_MAX;
-        if (isstart) {
+        if (a.dbg_ablate & 1) tokv = 7u;
+        else if (isstart) {
             if (len == 1) {
                 tokv = b0;  // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
             } else if (len <= 16) {
-                // exact key: the piece bytes themselves, zero padded to 16
-                const uint32_t keep = 8u * (uint32_t)(len & 3);
-                const uint32_t part = keep ? ((1u << keep) - 1u) : 0xFFFFFFFFu;  // mask of the last, partial dword
-                const int nd = (len + 3) >> 2;                                       // dwords that carry bytes
-                uint32_t k0 = d4, k1 = d4hi, k2 = d4b, k3 = d4c;
-                k0 &= nd == 1 ? part : 0xFFFFFFFFu;
-                k1 &= nd < 2 ? 0u : nd == 2 ? part : 0xFFFFFFFFu;
-                k2 &= nd < 3 ? 0u : nd == 3 ? part : 0xFFFFFFFFu;
-                k3 &= nd < 4 ? 0u : part;
+                // exact key: the piece bytes themselves, zero padded to 16 (lane + 4j is in my piece iff len > 4j)
+                const uint32_t k0 = d4m, k1 = len > 4 ? g1 : 0u, k2 = len > 8 ? g2 : 0u, k3 = len > 12 ? g3 : 0u;
                 tokv = tk_probe_key(t, k0, k1, k2, k3, (uint32_t)len);
             } else {
                 tokv = tk_probe_long(t, h1, h2, (uint32_t)len, a.bytes + w0 + lane);
@@ -699,7 +692,7 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         uint64_t A = 0;
         uint32_t tok = b0;
         const bool inmiss = inreg && tk_bit(Mi, ps);
-        if (Mi) {
+        if (Mi && !(a.dbg_ablate & 2)) {
             A = wv_ballot(inmiss);
             uint32_t prank = TK_RANK_MAX;
             if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
@@ -735,7 +728,7 @@ TK_DEV bool tk_encode_doc(const TkEncodeArgs& a, uint64_t d, int lane, const TkP
         const bool hitstart = isstart && tokv != TK_RANK_MAX;
         const bool istok = hitstart || (inmiss && tk_bit(A, lane));
         const uint64_t Tm = wv_ballot(istok);
-        if (istok) {
+        if (istok && !(a.dbg_ablate & 4)) {
             out[cursor + (uint32_t)tk_popc64(Tm & tk_lowmask(lane))] = (hitstart ? tokv : tok) + t.num_special;
         }
         cursor += (uint32_t)tk_popc64(Tm);

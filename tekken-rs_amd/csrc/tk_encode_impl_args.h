@@ -23,6 +23,7 @@ struct TkEncodeArgs {
     uint64_t scratch_words_per_wave;
     int add_bos, add_eos;
     int split_only;
+    int dbg_ablate;             // timing-only ablation bits (TK_DEBUG_ABLATE): 1 skip probes, 2 skip merges, 4 skip id stores
     TkTablesView t;
 };
 

@@ -235,6 +235,12 @@ __global__ void tk_wave_selftest_kernel(uint32_t* fail) {
     if (wv_ballot((lane & 1) == 0) != 0x5555555555555555ull) bad |= 8u;
     if (tk_wave_sum((uint32_t)lane, lane) != 2016u) bad |= 16u;
     if (tk_wave_min64(((uint64_t)(100 - lane) << 32) | (uint32_t)lane, lane) != (((uint64_t)37 << 32) | 63u)) bad |= 32u;
+    // DPP min reduction: minimum placed in every row / at both ends in turn
+    for (int at = 0; at < 64; at += 7) {
+        if (wv_min_u32(lane == at ? 5u : 1000u + (uint32_t)lane) != 5u) bad |= 64u;
+    }
+    if (wv_min_u32(0xFFFFFFFFu) != 0xFFFFFFFFu) bad |= 128u;
+    if (wv_readlane(v, 17) != 1017u) bad |= 256u;
     if (bad) atomicOr(fail, bad);
 }
 

@@ -21,6 +21,22 @@ TK_DEV uint64_t wv_first64(uint64_t v) {
     return ((uint64_t)wv_first((uint32_t)(v >> 32)) << 32) | (uint64_t)wv_first((uint32_t)v);
 }
 
+// value of `v` in lane `l`, l wave-uniform (v_readlane_b32: no LDS crossbar, result is scalar)
+TK_DEV uint32_t wv_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// minimum of `v` over all 64 lanes as a scalar: DPP row shifts inside the 4 rows of 16 lanes, then the
+// two row broadcasts; lane 63 ends up with the minimum (the classic GFX9 wave reduction, VALU only)
+TK_DEV uint32_t wv_min_u32(uint32_t v) {
+    uint32_t x = v, y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xF, 0xF, false); x = y < x ? y : x;  // row_shr:1
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xF, 0xF, false); x = y < x ? y : x;  // row_shr:2
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xF, 0xF, false); x = y < x ? y : x;  // row_shr:4
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xF, 0xF, false); x = y < x ? y : x;  // row_shr:8
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xA, 0xF, false); x = y < x ? y : x;  // row_bcast:15
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xC, 0xF, false); x = y < x ? y : x;  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // lane i receives lane i+1's value, lane 63 receives 0   (DPP wave_shl:1)
 TK_DEV uint32_t wv_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);

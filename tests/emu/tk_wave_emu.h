@@ -25,7 +25,7 @@
 
 namespace tkemu {
 
-enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC, OP_FIRST, OP_ATOMIC };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC, OP_FIRST, OP_ATOMIC, OP_MIN };
 
 struct Wave {
     ucontext_t sched;
@@ -141,6 +141,17 @@ TK_DEV uint32_t wv_first(uint32_t v) {
 }
 TK_DEV uint64_t wv_first64(uint64_t v) {
     return ((uint64_t)wv_first((uint32_t)(v >> 32)) << 32) | (uint64_t)wv_first((uint32_t)v);
+}
+
+TK_DEV uint32_t wv_readlane(uint32_t v, int l) { return wv_shfl(v, l); }
+
+TK_DEV uint32_t wv_min_u32(uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    w->dep_u32[w->cur] = v;
+    tkemu::yield_op(tkemu::OP_MIN);
+    uint32_t m = 0xFFFFFFFFu;
+    for (int l = 0; l < 64; ++l) m = tkemu::g_wave->snap_u32[l] < m ? tkemu::g_wave->snap_u32[l] : m;
+    return m;
 }
 
 TK_DEV uint32_t wv_up1(uint32_t v) {

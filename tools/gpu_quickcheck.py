@@ -66,6 +66,12 @@ def main():
         print("C2 slice: docs=%d bytes=%d ids=%d wall=%.2fms pipeline=%.2fms encode=%.2fms  -> %.1f MB/s (wall), %.1f MB/s (kernel)"
               % (n_docs, len(data), n_ids, dt * 1e3, tm["pipeline_ms"], tm["encode_kernel_ms"], len(data) / dt / 1e6,
                  len(data) / (tm["encode_kernel_ms"] * 1e-3) / 1e6), flush=True)
+    # PCIe-inclusive rate of the host-buffer entry (pageable input, pinned output; never the bench `value`)
+    for it in range(3):
+        t0 = time.time()
+        ids, oo = eng.encode_batch(data, offs, True, True)
+        dt = time.time() - t0
+        print("host entry tk_encode_batch (H2D + pipeline + D2H): %.1f ms -> %.1f MB/s PCIe-inclusive" % (dt * 1e3, len(data) / dt / 1e6), flush=True)
     t0 = time.time()
     sample = 20000
     eids, eoo = orc.encode_batch(data[:int(offs[sample])], offs[:sample + 1], True, True, threads=1)

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=2, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--decode-steps", type=int, default=5, help="extra leg: GPU batch decode of the produced ids (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = dry run of the N>1 code path with several ranks sharing one GPU (ids staged through host)")
     args = ap.parse_args()
@@ -164,6 +165,8 @@ def main():
                          "pipeline_ms": round(float(np.mean(pipe_ms)), 4)},
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
         }
+        if not distributed and args.decode_steps > 0:
+            out["decode"] = decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream)
         if not distributed and args.cpu_passes > 0:
             out.update(cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes))
         print(json.dumps(out), flush=True)
@@ -171,6 +174,27 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     tokz.close()
+
+
+def decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream):
+    """SURVEY 8 row f-1: batch Tekkenizer::decode of the ids just produced, ids resident in HBM.
+    Algorithmic bytes: 4 B per id read + 1 B per text byte written + two u64 offset arrays."""
+    import torch
+    ids = torch.as_tensor(v_ids, device="cuda").clone()
+    oo = torch.as_tensor(v_oo, device="cuda").clone()
+    ms = []
+    for it in range(args.decode_steps + 1):
+        v_b, v_bo = eng.decode_batch_device(ids.data_ptr(), oo.data_ptr(), n_docs, ids.numel(), tk.SpecialTokenPolicy.Ignore, stream)
+        if it:
+            ms.append(eng.last_timing()["pipeline_ms"])
+    out = torch.as_tensor(v_b, device="cuda")
+    ok = bool(out.numel() == n_bytes and torch.equal(out, d_bytes))
+    t = float(np.mean(ms)) * 1e-3
+    alg = 4 * ids.numel() + n_bytes + 16 * (n_docs + 1)
+    return {"metric": "output MB/s decoded (pipeline: len + scan + copy + validate)", "value": round(n_bytes / 1e6 / t, 1),
+            "ms": round(t * 1e3, 4), "round_trip_exact": ok,
+            "roofline": {"bound": "hbm", "achieved": round(alg / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 5)}}
 
 
 def cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes):

@@ -36,6 +36,10 @@ extern "C" {
 #define TK_ERR_TOKEN_NOT_FOUND (-9)  /* -> TokenizerError::TokenNotFound   (errors.rs:49-50) */
 #define TK_ERR_SPECIAL_POLICY (-10)  /* -> TokenizerError::SpecialTokenPolicy (errors.rs:53-54) */
 
+#define TK_POLICY_IGNORE 0  /* SpecialTokenPolicy::Ignore  (src/special_tokens.rs:128-136) */
+#define TK_POLICY_KEEP 1    /* SpecialTokenPolicy::Keep  */
+#define TK_POLICY_RAISE 2   /* SpecialTokenPolicy::Raise */
+
 typedef struct tk_ctx tk_ctx;
 
 /* ------------------------------------------------------------------------------------------
@@ -85,6 +89,33 @@ int tk_encode_batch_device(tk_ctx* ctx, const void* d_bytes, const void* d_doc_o
                            uint64_t n_bytes, int add_bos, int add_eos, void* hip_stream, void** d_ids,
                            void** d_out_offsets, uint64_t* n_ids);
 
+/* ---- decode: batch form of Tekkenizer::decode (src/tekkenizer.rs:436-560) ----
+ * The engine needs the special-token strings for TK_POLICY_KEEP: entry i is the string of the special token
+ * at POSITION i of the reference's all_special_tokens vector (src/tekkenizer.rs:108-116, 536-540);
+ * n must equal num_special_tokens.  Copied. */
+int tk_ctx_set_special_tokens(tk_ctx* ctx, const uint8_t* strings_blob, const uint32_t* string_offsets, uint32_t n);
+
+typedef struct tk_text_result {
+    uint8_t* bytes;     /* concatenated UTF-8 text of all documents */
+    uint64_t* offsets;  /* n_docs + 1: document d is bytes[offsets[d] .. offsets[d+1]) */
+    uint64_t n_bytes;
+    uint64_t n_docs;
+} tk_text_result;
+
+/* For every document d (ids[id_offsets[d] .. id_offsets[d+1])) exactly the String that
+ * Tekkenizer::decode(ids_d, policy) returns.  If ANY document would make the reference return Err, the call
+ * fails as a whole and *bad_doc (optional) receives the first such document:
+ *   TK_ERR_SPECIAL_POLICY  a special id under TK_POLICY_RAISE          (src/tekkenizer.rs:531-535)
+ *   TK_ERR_RUNTIME         an id outside the vocabulary, or a non-special run that is not valid UTF-8
+ *                          (CoreBPE::decode -> TokenizerError::Tokenizers, src/tekkenizer.rs:552-555) */
+int tk_decode_batch(tk_ctx* ctx, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs, int policy,
+                    tk_text_result* out, uint64_t* bad_doc);
+void tk_free_text_result(tk_text_result* r);
+/* Same with ids resident in HBM; outputs are context-owned device buffers valid until the next call. */
+int tk_decode_batch_device(tk_ctx* ctx, const void* d_ids, const void* d_id_offsets, uint64_t n_docs, uint64_t n_ids,
+                           int policy, void* hip_stream, void** d_bytes, void** d_out_offsets, uint64_t* n_bytes,
+                           uint64_t* bad_doc);
+
 /* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
 int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);
@@ -103,10 +134,6 @@ int tk_split_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offset
  * ---------------------------------------------------------------------------------------- */
 typedef struct tk_tokenizer tk_tokenizer;
 
-#define TK_POLICY_IGNORE 0  /* SpecialTokenPolicy::Ignore  (src/special_tokens.rs:128-136) */
-#define TK_POLICY_KEEP 1    /* SpecialTokenPolicy::Keep  */
-#define TK_POLICY_RAISE 2   /* SpecialTokenPolicy::Raise */
-
 /* Tekkenizer::from_file (src/tekkenizer.rs:222-248).  device_id < 0 => host-only object
  * (loader, decode and accessors work; encode returns TK_ERR_NO_DEVICE). */
 int tk_tokenizer_from_file(const char* path, int device_id, tk_tokenizer** out);
@@ -124,6 +151,10 @@ int tk_tokenizer_encode(tk_tokenizer* t, const char* text, size_t len, int add_b
 int tk_tokenizer_encode_batch(tk_tokenizer* t, const uint8_t* bytes, const uint64_t* doc_offsets,
                               uint64_t n_docs, int add_bos, int add_eos, tk_result* out);
 void tk_free_ids(uint32_t* ids);
+
+/* Batch decode on the GPU (needs a device-backed tokenizer); see tk_decode_batch. */
+int tk_tokenizer_decode_batch(tk_tokenizer* t, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs,
+                              int policy, tk_text_result* out, uint64_t* bad_doc);
 
 /* Tekkenizer::decode (src/tekkenizer.rs:436-443); *text is malloc'ed (not NUL terminated beyond
  * *len, but a trailing NUL is added for convenience), free with tk_free_text. */

@@ -115,3 +115,35 @@ def fnv1a(ids: np.ndarray) -> int:
         ids_p = np.zeros(1, np.uint32)
         return lib().tk_oracle_fnv1a(_p(ids_p, ctypes.c_uint32), 0)
     return lib().tk_oracle_fnv1a(_p(ids, ctypes.c_uint32), len(ids))
+
+
+def decode_ref(token_bytes, special_strings, num_special, ids, policy):
+    """Pure-Python restatement of Tekkenizer::decode (reference src/tekkenizer.rs:436-560) for tests:
+    policy 0 Ignore / 1 Keep / 2 Raise.  Returns bytes, or raises ValueError("special"/"key"/"utf8")."""
+    out = []
+    g0 = 0
+    ids = list(ids)
+    while g0 < len(ids):
+        sp = ids[g0] < num_special                      # :474
+        g1 = g0 + 1
+        while g1 < len(ids) and (ids[g1] < num_special) == sp:
+            g1 += 1
+        if sp:
+            if policy == 2:
+                raise ValueError("special")            # :531-535
+            if policy == 1:
+                out.extend(special_strings[i].encode("utf-8") for i in ids[g0:g1])   # :536-540 (by position)
+        else:
+            run = b""
+            for i in ids[g0:g1]:
+                r = i - num_special                    # :548-551
+                if r >= len(token_bytes):
+                    raise ValueError("key")
+                run += token_bytes[r]
+            try:
+                run.decode("utf-8")                    # CoreBPE::decode -> String::from_utf8, :552-555
+            except UnicodeDecodeError:
+                raise ValueError("utf8")
+            out.append(run)
+        g0 = g1
+    return b"".join(out)

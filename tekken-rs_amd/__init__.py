@@ -57,6 +57,11 @@ class SpecialTokenPolicy(enum.IntEnum):
     Raise = 2
 
 
+class _TextResult(ctypes.Structure):
+    _fields_ = [("bytes", ctypes.POINTER(ctypes.c_uint8)), ("offsets", ctypes.POINTER(ctypes.c_uint64)),
+                ("n_bytes", ctypes.c_uint64), ("n_docs", ctypes.c_uint64)]
+
+
 class _Result(ctypes.Structure):
     _fields_ = [("ids", ctypes.POINTER(ctypes.c_uint32)), ("offsets", ctypes.POINTER(ctypes.c_uint64)),
                 ("n_ids", ctypes.c_uint64), ("n_docs", ctypes.c_uint64)]
@@ -102,6 +107,16 @@ def lib():
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    L.tk_ctx_set_special_tokens.restype = ctypes.c_int
+    L.tk_ctx_set_special_tokens.argtypes = [vp, u8p, u32p, ctypes.c_uint32]
+    L.tk_decode_batch.restype = ctypes.c_int
+    L.tk_decode_batch.argtypes = [vp, u32p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_TextResult), u64p]
+    L.tk_free_text_result.argtypes = [ctypes.POINTER(_TextResult)]
+    L.tk_decode_batch_device.restype = ctypes.c_int
+    L.tk_decode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, vp, ctypes.POINTER(vp),
+                                         ctypes.POINTER(vp), u64p, u64p]
+    L.tk_tokenizer_decode_batch.restype = ctypes.c_int
+    L.tk_tokenizer_decode_batch.argtypes = [vp, u32p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_TextResult), u64p]
     L.tk_last_timing.restype = ctypes.c_int
     L.tk_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.tk_last_stats.restype = ctypes.c_int
@@ -250,6 +265,56 @@ class Engine:
         p_ids, p_oo, n = self.encode_batch_device(d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos, add_eos, stream)
         return DeviceView(p_ids, n, "<i4"), DeviceView(p_oo, n_docs + 1, "<i8")
 
+    def set_special_tokens(self, strings):
+        """Special-token strings by position (needed by decode with SpecialTokenPolicy.Keep)."""
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in strings]
+        offs = np.zeros(len(raw) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(x) for x in raw], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(raw) or b"\0", dtype=np.uint8).copy()
+        rc = lib().tk_ctx_set_special_tokens(self._h, _p(blob, ctypes.c_uint8), _p(offs, ctypes.c_uint32), len(raw))
+        if rc != TK_OK:
+            raise self._err(rc)
+
+    def decode_batch(self, ids, offs, policy=SpecialTokenPolicy.Ignore):
+        """Batch Tekkenizer::decode on the GPU: (uint32 ids, uint64 offsets[D+1]) -> (uint8 bytes, uint64 offsets[D+1])."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        res = _TextResult()
+        bad = ctypes.c_uint64(0)
+        ibuf = ids if len(ids) else np.zeros(1, np.uint32)
+        rc = lib().tk_decode_batch(self._h, _p(ibuf, ctypes.c_uint32), _p(offs, ctypes.c_uint64), len(offs) - 1, int(policy),
+                                   ctypes.byref(res), ctypes.byref(bad))
+        if rc != TK_OK:
+            e = self._err(rc)
+            e.bad_doc = int(bad.value)
+            raise e
+        n, D = int(res.n_bytes), int(res.n_docs)
+        data = np.ctypeslib.as_array(res.bytes, shape=(max(n, 1),))[:n].copy()
+        oo = np.ctypeslib.as_array(res.offsets, shape=(D + 1,)).copy()
+        lib().tk_free_text_result(ctypes.byref(res))
+        return data, oo
+
+    def decode_docs(self, id_lists, policy=SpecialTokenPolicy.Ignore):
+        offs = np.zeros(len(id_lists) + 1, np.uint64)
+        if id_lists:
+            offs[1:] = np.cumsum([len(x) for x in id_lists], dtype=np.uint64)
+        ids = np.array([i for x in id_lists for i in x], dtype=np.uint32)
+        data, oo = self.decode_batch(ids, offs, policy)
+        raw = data.tobytes()
+        return [raw[int(oo[d]):int(oo[d + 1])] for d in range(len(id_lists))]
+
+    def decode_batch_device(self, d_ids_ptr, d_offs_ptr, n_docs, n_ids, policy=SpecialTokenPolicy.Ignore, stream=0):
+        """ids resident in HBM -> (bytes view uint8[n_bytes], offsets view int64[n_docs+1]) context-owned."""
+        d_b, d_o, n, bad = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = lib().tk_decode_batch_device(self._h, ctypes.c_void_p(d_ids_ptr), ctypes.c_void_p(d_offs_ptr), n_docs, n_ids,
+                                          int(policy), ctypes.c_void_p(stream), ctypes.byref(d_b), ctypes.byref(d_o),
+                                          ctypes.byref(n), ctypes.byref(bad))
+        if rc != TK_OK:
+            e = self._err(rc)
+            e.bad_doc = int(bad.value)
+            raise e
+        return DeviceView(d_b.value, int(n.value), "|u1"), DeviceView(d_o.value, n_docs + 1, "<i8")
+
     def last_timing(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().tk_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
@@ -352,6 +417,13 @@ class Tekkenizer:
         out = ctypes.string_at(text, n.value).decode("utf-8")
         lib().tk_free_text(text)
         return out
+
+    def decode_batch(self, id_lists, policy=SpecialTokenPolicy.Ignore):
+        """Batch decode on the GPU: list of id lists -> list of str (an addition; the reference decodes one at a time)."""
+        eng = self.engine()
+        if eng is None:
+            raise TokenizerError(TK_ERR_NO_DEVICE, "tokenizer was created without a device (host-only object)")
+        return [b.decode("utf-8") for b in eng.decode_docs(id_lists, policy)]
 
     def _piece(self, fn, *args):
         text = ctypes.c_void_p()

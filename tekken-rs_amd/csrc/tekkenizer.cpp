@@ -532,6 +532,16 @@ Tekkenizer* Tekkenizer::create(const std::vector<TokenInfo>& vocab_in, const std
             delete t;
             return nullptr;
         }
+        // special-token strings BY POSITION, for the device decode path (Keep policy, :536-540)
+        std::string sblob;
+        std::vector<uint32_t> soffs(1, 0);
+        for (const auto& s : all) { sblob += s.token_str; soffs.push_back((uint32_t)sblob.size()); }
+        rc = tk_ctx_set_special_tokens(t->ctx_, (const uint8_t*)sblob.data(), soffs.data(), (uint32_t)all.size());
+        if (rc != TK_OK) {
+            err = mk(rc, std::string("special tokens upload failed: ") + tk_last_error(t->ctx_));
+            delete t;
+            return nullptr;
+        }
     }
     return t;
 }
@@ -765,6 +775,15 @@ extern "C" int tk_tokenizer_decode(tk_tokenizer* h, const uint32_t* ids, size_t 
 }
 
 extern "C" void tk_free_text(char* text) { free(text); }
+
+extern "C" int tk_tokenizer_decode_batch(tk_tokenizer* h, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs,
+                                         int policy, tk_text_result* out, uint64_t* bad_doc) {
+    if (!h || !id_offsets || !out) return TK_ERR_INVALID_ARG;
+    if (!h->t->ctx()) { h->err = "tokenizer was created without a device (host-only object)"; return TK_ERR_NO_DEVICE; }
+    int rc = tk_decode_batch(h->t->ctx(), ids, id_offsets, n_docs, policy, out, bad_doc);
+    if (rc != TK_OK) h->err = tk_last_error(h->t->ctx());
+    return rc;
+}
 
 extern "C" uint32_t tk_tokenizer_vocab_size(const tk_tokenizer* h) { return h ? h->t->vocab_size() : 0; }
 extern "C" uint32_t tk_tokenizer_num_special_tokens(const tk_tokenizer* h) { return h ? h->t->num_special_tokens() : 0; }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/tekken_hip.h"
+#include "tekkenizer.hpp"
 #include "tk_engine.h"
 #include "tk_kernels.h"
 #include "tk_tables.h"
@@ -52,7 +53,9 @@ struct tk_ctx {
     std::string err;
     TkHostTables host;
     TkTablesView dview;
-    DevBuf t_uc1, t_uc2, t_key, t_long, t_pair, t_pair2, t_blob;
+    DevBuf t_uc1, t_uc2, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
+    bool have_specials = false;
+    DevBuf dec_lens, dec_boff, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -118,7 +121,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
         (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
-        (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())))
+        (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())) ||
+        (rc = upload(c, c->t_offs, h.offs.data(), h.offs.size() * 4)))
         return fail(rc);
     c->dview = h.host_view();
     c->dview.uc_stage1 = (const uint16_t*)c->t_uc1.p;
@@ -150,7 +154,9 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob,
+    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
+                      &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_boff, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
+                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg};
     for (DevBuf* b : bufs) b->release();
@@ -395,4 +401,194 @@ extern "C" int tk_split_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* d
     if (n_bytes) TK_HIP(c, hipMemcpyAsync(out_is_start, c->dbg.p, n_bytes, hipMemcpyDeviceToHost, c->stream));
     TK_HIP(c, hipStreamSynchronize(c->stream));
     return TK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------
+extern "C" int tk_ctx_set_special_tokens(tk_ctx* c, const uint8_t* blob, const uint32_t* offs, uint32_t n) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!offs || n != c->host.num_special || (!blob && n && offs[n])) {
+        c->err = "special token strings: need exactly num_special_tokens entries";
+        return TK_ERR_INVALID_ARG;
+    }
+    TK_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = upload(c, c->t_spblob, blob, n ? offs[n] : 0)) || (rc = upload(c, c->t_spoffs, offs, ((size_t)n + 1) * 4))) return rc;
+    c->have_specials = true;
+    return TK_OK;
+}
+
+static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_offs, uint64_t n_docs, uint64_t n_ids, int policy,
+                      hipStream_t s, uint64_t* n_bytes, uint64_t* bad_doc) {
+    if (policy < TK_POLICY_IGNORE || policy > TK_POLICY_RAISE) { c->err = "invalid policy"; return TK_ERR_INVALID_ARG; }
+    if (policy == TK_POLICY_KEEP && !c->have_specials) {
+        c->err = "TK_POLICY_KEEP needs tk_ctx_set_special_tokens first";
+        return TK_ERR_INVALID_ARG;
+    }
+    TK_HIP(c, c->dec_lens.reserve((n_ids + 1) * 4));
+    TK_HIP(c, c->dec_boff.reserve((n_ids + 2) * 8));
+    TK_HIP(c, c->dec_offs.reserve((n_docs + 1) * 8));
+    TK_HIP(c, c->dec_err.reserve(64));
+    TK_HIP(c, c->block_sums.reserve((n_ids / 2048 + 4) * 8));
+    TkDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ids = d_ids;
+    a.id_offs = d_id_offs;
+    a.n_ids = n_ids;
+    a.n_docs = n_docs;
+    a.lens = (uint32_t*)c->dec_lens.p;
+    a.boff = (const uint64_t*)c->dec_boff.p;
+    a.out_offs = (uint64_t*)c->dec_offs.p;
+    a.err = (unsigned long long*)c->dec_err.p;
+    a.tok_blob = (const uint8_t*)c->t_blob.p;
+    a.tok_offs = (const uint32_t*)c->t_offs.p;
+    a.sp_blob = (const uint8_t*)c->t_spblob.p;
+    a.sp_offs = (const uint32_t*)c->t_spoffs.p;
+    a.n_ranks = c->host.n_ranks;
+    a.num_special = c->host.num_special;
+    a.policy = policy;
+    TK_HIP(c, hipMemsetAsync(c->dec_err.p, 0xFF, 24, s));
+    TK_HIP(c, hipEventRecord(c->ev[0], s));
+    TK_HIP(c, tk_launch_decode_len(a, s));
+    TK_HIP(c, tk_launch_scan(a.lens, n_ids, (uint64_t*)c->dec_boff.p, (uint64_t*)c->block_sums.p, s));
+    uint64_t total = 0;
+    unsigned long long err[3] = {~0ull, ~0ull, ~0ull};
+    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_boff.p + n_ids, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 16, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    auto doc_of = [&](uint64_t id_index, uint64_t* out) -> int {
+        // first document whose id range contains id_index: binary search on the device offsets (rare path)
+        uint64_t lo = 0, hi = n_docs;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) / 2, v = 0;
+            TK_HIP(c, hipMemcpy(&v, d_id_offs + mid + 1, 8, hipMemcpyDeviceToHost));
+            if (v <= id_index) lo = mid + 1; else hi = mid;
+        }
+        *out = lo;
+        return TK_OK;
+    };
+    TK_HIP(c, c->dec_bytes.reserve(total + 64));
+    TK_HIP(c, c->dec_bits.reserve((total / 32 + 4) * 4));
+    a.out_bytes = (uint8_t*)c->dec_bytes.p;
+    a.run_bits = (uint32_t*)c->dec_bits.p;
+    TK_HIP(c, hipMemsetAsync(c->dec_bits.p, 0, (total / 32 + 4) * 4, s));
+    TK_HIP(c, tk_launch_decode_copy(a, s));
+    TK_HIP(c, tk_launch_decode_validate(a, s));
+    TK_HIP(c, hipEventRecord(c->ev[2], s));
+    TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 24, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[0], c->ev[2]);
+    c->encode_ms = 0.f;
+    if (err[0] != ~0ull || err[1] != ~0ull || err[2] != ~0ull) {
+        // Some document makes the reference return Err.  The GPU found WHICH documents; the class of the
+        // error of the first one is decided by walking that single document's groups in the reference's
+        // order (src/tekkenizer.rs:463-560) -- error classification only, no result is computed here.
+        uint64_t first = err[2];
+        for (int k = 0; k < 2; ++k) {
+            if (err[k] == ~0ull) continue;
+            uint64_t d = 0;
+            int rc = doc_of(err[k], &d);
+            if (rc != TK_OK) return rc;
+            if (d < first) first = d;
+        }
+        if (bad_doc) *bad_doc = first;
+        uint64_t range[2] = {0, 0};
+        TK_HIP(c, hipMemcpy(range, d_id_offs + first, 16, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> hid((size_t)(range[1] - range[0]));
+        if (!hid.empty()) TK_HIP(c, hipMemcpy(hid.data(), d_ids + range[0], hid.size() * 4, hipMemcpyDeviceToHost));
+        const TkHostTables& h = c->host;
+        size_t g0 = 0;
+        while (g0 < hid.size()) {
+            const bool sp = hid[g0] < h.num_special;
+            size_t g1 = g0 + 1;
+            while (g1 < hid.size() && (hid[g1] < h.num_special) == sp) ++g1;
+            if (sp) {
+                if (policy == TK_POLICY_RAISE) {
+                    c->err = "Decoding tokens that contain special tokens is not allowed (document " + std::to_string(first) + ")";
+                    return TK_ERR_SPECIAL_POLICY;
+                }
+            } else {
+                std::string run;
+                for (size_t k = g0; k < g1; ++k) {
+                    const uint32_t r = hid[k] - h.num_special;
+                    if (r >= h.n_ranks) {
+                        c->err = "DecodeKeyError: invalid token for decoding: " + std::to_string(r) + " (document " + std::to_string(first) + ")";
+                        return TK_ERR_RUNTIME;
+                    }
+                    run.append((const char*)h.blob.data() + h.offs[r], h.offs[r + 1] - h.offs[r]);
+                }
+                if (!tekken::utf8_valid((const uint8_t*)run.data(), run.size())) {
+                    c->err = "FromUtf8Error: invalid utf-8 sequence (document " + std::to_string(first) + ")";
+                    return TK_ERR_RUNTIME;
+                }
+            }
+            g0 = g1;
+        }
+        c->err = "decode: device flagged document " + std::to_string(first) + " but the host walk found no error";
+        return TK_ERR_RUNTIME;
+    }
+    *n_bytes = total;
+    return TK_OK;
+}
+
+extern "C" int tk_decode_batch_device(tk_ctx* c, const void* d_ids, const void* d_id_offsets, uint64_t n_docs, uint64_t n_ids,
+                                      int policy, void* hip_stream, void** d_bytes, void** d_out_offsets, uint64_t* n_bytes,
+                                      uint64_t* bad_doc) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!d_id_offsets || (!d_ids && n_ids) || !d_bytes || !d_out_offsets || !n_bytes) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    TK_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    int rc = run_decode(c, (const uint32_t*)d_ids, (const uint64_t*)d_id_offsets, n_docs, n_ids, policy, s, n_bytes, bad_doc);
+    if (rc != TK_OK) return rc;
+    *d_bytes = c->dec_bytes.p;
+    *d_out_offsets = c->dec_offs.p;
+    return TK_OK;
+}
+
+extern "C" int tk_decode_batch(tk_ctx* c, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs, int policy,
+                               tk_text_result* out, uint64_t* bad_doc) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!id_offsets || !out || (!ids && id_offsets[n_docs])) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    memset(out, 0, sizeof(*out));
+    int rc = check_offsets(c, id_offsets, n_docs);
+    if (rc != TK_OK) return rc;
+    TK_HIP(c, hipSetDevice(c->device));
+    const uint64_t n_ids = id_offsets[n_docs];
+    TK_HIP(c, c->dec_in_ids.reserve((n_ids + 1) * 4));
+    TK_HIP(c, c->dec_in_offs.reserve((n_docs + 1) * 8));
+    if (n_ids) TK_HIP(c, hipMemcpyAsync(c->dec_in_ids.p, ids, n_ids * 4, hipMemcpyHostToDevice, c->stream));
+    TK_HIP(c, hipMemcpyAsync(c->dec_in_offs.p, id_offsets, (n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t n_bytes = 0;
+    rc = run_decode(c, (const uint32_t*)c->dec_in_ids.p, (const uint64_t*)c->dec_in_offs.p, n_docs, n_ids, policy, c->stream,
+                    &n_bytes, bad_doc);
+    if (rc != TK_OK) return rc;
+    uint8_t* hb = nullptr;
+    uint64_t* ho = nullptr;
+    TK_HIP(c, hipHostMalloc((void**)&hb, n_bytes ? n_bytes : 1, hipHostMallocDefault));
+    hipError_t e = hipHostMalloc((void**)&ho, (n_docs + 1) * 8, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipHostFree(hb); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    if (n_bytes) e = hipMemcpyAsync(hb, c->dec_bytes.p, n_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ho, c->dec_offs.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipHostFree(hb); (void)hipHostFree(ho);
+        c->err = std::string("result copy failed: ") + hipGetErrorString(e);
+        return TK_ERR_RUNTIME;
+    }
+    out->bytes = hb;
+    out->offsets = ho;
+    out->n_bytes = n_bytes;
+    out->n_docs = n_docs;
+    return TK_OK;
+}
+
+extern "C" void tk_free_text_result(tk_text_result* r) {
+    if (!r) return;
+    if (r->bytes) (void)hipHostFree(r->bytes);
+    if (r->offsets) (void)hipHostFree(r->offsets);
+    memset(r, 0, sizeof(*r));
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/tekken_hip.h"
 #include "tk_encode_impl_args.h"
 
 // mode 0: pass 1; mode 1: pass 2 (scratch-backed, every launched wave owns a scratch slice);
@@ -21,6 +22,28 @@ hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, 
 // UTF-8 validation of every document; *d_bad receives the number of invalid documents
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s);
+
+// ---- decode path (tk_decode.hip) ----
+struct TkDecodeArgs {
+    const uint32_t* ids;       // [n_ids] packed token ids of all documents
+    const uint64_t* id_offs;   // [n_docs + 1]
+    uint64_t n_ids, n_docs;
+    uint32_t* lens;            // [n_ids] bytes contributed by every id
+    const uint64_t* boff;      // [n_ids + 1] exclusive scan of lens
+    uint8_t* out_bytes;        // [total bytes]
+    uint64_t* out_offs;        // [n_docs + 1]
+    uint32_t* run_bits;        // bitmap over output bytes: 1 = a run starts here (hard UTF-8 boundary)
+    unsigned long long* err;   // [3] see tk_decode.hip
+    const uint8_t* tok_blob;   // token bytes by rank
+    const uint32_t* tok_offs;  // [n_ranks + 1]
+    const uint8_t* sp_blob;    // special token strings by POSITION (reference src/tekkenizer.rs:536-540)
+    const uint32_t* sp_offs;   // [num_special + 1]
+    uint32_t n_ranks, num_special;
+    int policy;                // TK_POLICY_*
+};
+hipError_t tk_launch_decode_len(const TkDecodeArgs& a, hipStream_t s);
+hipError_t tk_launch_decode_copy(const TkDecodeArgs& a, hipStream_t s);      // copy + document offsets
+hipError_t tk_launch_decode_validate(const TkDecodeArgs& a, hipStream_t s);
 
 // max document length over the deferred documents (atomicMax into *d_out, which must be zeroed)
 hipError_t tk_launch_defer_maxlen(const uint32_t* defer_list, uint32_t n, const uint64_t* doc_offs, uint32_t* d_out,

@@ -1,0 +1,122 @@
+"""GPU batch decode through the C ABI against a restatement of the
+reference's Tekkenizer::decode (oracle/tk_oracle.py decode_ref, reference src/tekkenizer.rs:436-560):
+SpecialTokenPolicy behaviour, per-run UTF-8 validity, error classes, round trips at full size."""
+import json
+
+import numpy as np
+import pytest
+
+import corpus
+import helpers
+import tk_oracle
+
+pytestmark = pytest.mark.gpu
+
+SPECIALS = ["<unk>", "<s>", "</s>", "[INST]", "[/INST]", "é🚀"] + ["<SPECIAL_%d>" % i for i in range(6, 1000)]
+
+
+@pytest.fixture(scope="module")
+def eng(tk, test_vocab):
+    e = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    e.set_special_tokens(SPECIALS)
+    yield e
+    e.close()
+
+
+def ref(test_vocab, ids, policy):
+    return tk_oracle.decode_ref(test_vocab["tokens"], SPECIALS, test_vocab["num_special"], ids, policy)
+
+
+def test_round_trip_and_policies(tk, eng, test_vocab):
+    orc = helpers.oracle_for(test_vocab)
+    docs = helpers.mixed_docs(80, 30, 60, max_len=20000) + helpers.random_unicode_docs(300)
+    id_lists = [orc.encode(d, True, True) for d in docs]
+    P = tk.SpecialTokenPolicy
+    assert eng.decode_docs(id_lists, P.Ignore) == docs                      # decode(encode(x)) == x (tests/test_tekken.rs)
+    kept = eng.decode_docs(id_lists, P.Keep)
+    assert kept == [b"<s>" + d + b"</s>" for d in docs]
+    with pytest.raises(tk.TokenizerError) as e:
+        eng.decode_docs(id_lists, P.Raise)
+    assert e.value.kind == "SpecialTokenPolicy" and e.value.bad_doc == 0
+    body = [x[1:-1] for x in id_lists]
+    assert eng.decode_docs(body, P.Raise) == docs
+    assert eng.decode_docs([], P.Ignore) == [] and eng.decode_docs([[], [1, 2], []], P.Ignore) == [b"", b"", b""]
+    assert eng.decode_docs([[1, 5, 2]], P.Keep) == ["<s>é🚀</s>".encode()]
+
+
+def test_per_run_utf8_and_error_classes(tk, eng, test_vocab):
+    ns = test_vocab["num_special"]
+    P = tk.SpecialTokenPolicy
+    c3, a9 = ns + 0xC3, ns + 0xA9
+    assert eng.decode_docs([[c3, a9]], P.Ignore) == ["é".encode()]
+    # a special token splits the code point into two runs: each run alone is invalid (src/tekkenizer.rs:552-555)
+    for pol in (P.Ignore, P.Keep):
+        with pytest.raises(tk.TokenizerError) as e:
+            eng.decode_docs([[ns + 97], [c3, 1, a9], [ns + 98]], pol)
+        assert e.value.kind == "Tokenizers" and e.value.bad_doc == 1
+    cases = [[c3], [a9], [ns + 0xE2, ns + 0x82], [ns + 0xC0, ns + 0xAF], [ns + 0xED, ns + 0xA0, ns + 0x80],
+             [ns + 0xF4, ns + 0x90, ns + 0x80, ns + 0x80], [ns + 97, ns + 0x80, ns + 98], [ns + 0xFF]]
+    for ids in cases:
+        with pytest.raises(ValueError):
+            ref(test_vocab, ids, 0)
+        with pytest.raises(tk.TokenizerError) as e:
+            eng.decode_docs([[ns + 120], ids], P.Ignore)
+        assert e.value.kind == "Tokenizers" and e.value.bad_doc == 1, ids
+    with pytest.raises(tk.TokenizerError) as e:                              # id outside the vocabulary
+        eng.decode_docs([[ns + len(test_vocab["tokens"]) + 5]], P.Ignore)
+    assert e.value.kind == "Tokenizers"
+    # the FIRST offending group decides the class: Raise-special before / after an invalid run
+    with pytest.raises(tk.TokenizerError) as e:
+        eng.decode_docs([[1, c3]], P.Raise)
+    assert e.value.kind == "SpecialTokenPolicy"
+    with pytest.raises(tk.TokenizerError) as e:
+        eng.decode_docs([[c3, 1]], P.Raise)
+    assert e.value.kind == "Tokenizers"
+
+
+def test_random_id_sequences_match_reference_restatement(tk, eng, test_vocab):
+    rng = np.random.default_rng(3)
+    ns, nr = test_vocab["num_special"], len(test_vocab["tokens"])
+    for policy in (0, 1, 2):
+        for _ in range(150):
+            n = int(rng.integers(0, 30))
+            ids = [int(rng.integers(0, 6)) if rng.random() < 0.15 else ns + int(rng.integers(0, nr)) for _ in range(n)]
+            try:
+                exp = ref(test_vocab, ids, policy)
+            except ValueError as ex:
+                with pytest.raises(tk.TokenizerError) as e:
+                    eng.decode_docs([ids], policy)
+                assert (e.value.kind == "SpecialTokenPolicy") == (str(ex) == "special"), (ids, str(ex))
+                continue
+            assert eng.decode_docs([ids], policy) == [exp], ids
+
+
+def test_tokenizer_level_batch_decode(tk, small_vocab):
+    from test_host_tokenizer import model
+    t = tk.Tekkenizer.from_json(json.dumps(model(small_vocab["tokens"])), device=0)
+    ids = t.encode_batch(["hello world", "", "héllo 🚀"], True, True)
+    assert t.decode_batch(ids, tk.SpecialTokenPolicy.Ignore) == ["hello world", "", "héllo 🚀"]
+    assert t.decode_batch(ids, tk.SpecialTokenPolicy.Keep)[0] == "<s>hello world</s>"
+    assert [t.decode(x, tk.SpecialTokenPolicy.Keep) for x in ids] == t.decode_batch(ids, tk.SpecialTokenPolicy.Keep)
+    t.close()
+
+
+def test_full_size_round_trip_device_resident(tk, bench_vocab):
+    """C2 at full size: encode 1 M x 512 B on the GPU, decode the ids on the GPU, compare bytes and offsets."""
+    import torch
+    e = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
+    n_docs = 1_000_000
+    data, offs = corpus.generate("ascii", n_docs, 512, seed=corpus.BASE_SEED + 1)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    v_ids, v_oo = e.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, len(data), True, True, st)
+    ids = torch.as_tensor(v_ids, device="cuda").clone()
+    oo = torch.as_tensor(v_oo, device="cuda").clone()
+    v_b, v_bo = e.decode_batch_device(ids.data_ptr(), oo.data_ptr(), n_docs, ids.numel(), tk.SpecialTokenPolicy.Ignore, st)
+    out = torch.as_tensor(v_b, device="cuda")
+    out_offs = torch.as_tensor(v_bo, device="cuda")
+    assert out.numel() == len(data) and torch.equal(out, d_bytes)
+    assert torch.equal(out_offs, d_offs)
+    assert e.last_timing()["pipeline_ms"] > 0
+    e.close()

@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
     ap.add_argument("--doc-len", type=int, default=512)
     ap.add_argument("--kind", default="ascii", choices=["ascii", "mixed", "zipf"])
-    ap.add_argument("--cpu-passes", type=int, default=2, help="oracle passes over the CPU sample (0 = skip)")
+    ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
     ap.add_argument("--decode-steps", type=int, default=5, help="extra leg: GPU batch decode of the produced ids (0 = skip)")

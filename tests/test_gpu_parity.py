@@ -196,3 +196,37 @@ def test_device_resident_entry_and_full_size_properties(tk, eng_bench, bench_voc
         assert tk_oracle.fnv1a(got) == tk_oracle.fnv1a(eids)
     tm = eng_bench.last_timing()
     assert tm["encode_kernel_ms"] > 0 and tm["pipeline_ms"] >= tm["encode_kernel_ms"]
+
+
+def test_invalid_utf8_without_validation_is_safe(eng_small):
+    """Callers that skip validation and pass malformed bytes get unspecified ids but no crash, no hang,
+    and the id count stays within the documented bound (bytes + 2 per document)."""
+    rng = np.random.default_rng(9)
+    docs = [bytes(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8)) for _ in range(200)]
+    docs += [b"\x80" * 500, b"\xf0" * 200, b"\xe4\xb8" * 100, b"a\xc3", b"\xff\xfe\xfd"]
+    out = eng_small.encode_docs(docs, True, True)
+    for d, ids in zip(docs, out):
+        assert 2 <= len(ids) <= len(d) + 2 and ids[0] == 1 and ids[-1] == 2
+
+
+def test_bench_contract_small(tk):
+    """bench.py prints exactly one JSON line with the contract's keys (small workload)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--docs", "20000", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample-docs", "5000", "--cpu-passes", "1", "--decode-steps", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "u8" and j["vs_baseline"] is None
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and "workload" in j["config"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["bit_exact_vs_cpu"] is True
+    assert j["decode"]["round_trip_exact"] is True

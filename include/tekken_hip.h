@@ -82,8 +82,8 @@ void tk_free_result(tk_result* r);
 
 /* Same computation with inputs already resident in HBM (hipMalloc'ed on the context's device):
  * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64.  Work is enqueued on
- * `hip_stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the
- * stream has drained.  *d_ids / *d_out_offsets are device buffers owned by the context, valid
+ * `hip_stream` (a hipStream_t; NULL = HIP's null stream, so the work is ordered after whatever the
+ * caller already enqueued there) and the call returns after the stream has drained.  *d_ids / *d_out_offsets are device buffers owned by the context, valid
  * until the next call on it; *n_ids = total ids. */
 int tk_encode_batch_device(tk_ctx* ctx, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
                            uint64_t n_bytes, int add_bos, int add_eos, void* hip_stream, void** d_ids,

@@ -55,7 +55,7 @@ struct tk_ctx {
     TkTablesView dview;
     DevBuf t_uc1, t_uc2, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
     bool have_specials = false;
-    DevBuf dec_lens, dec_boff, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
+    DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -155,7 +155,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
-                      &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_boff, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
+                      &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg};
@@ -271,7 +271,7 @@ extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void
     }
     if (n_docs >= 0xFFFFFFF0ull) { c->err = "too many documents in one batch"; return TK_ERR_INVALID_ARG; }
     TK_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream;  // NULL = HIP's null stream: ordered after the caller's own work on it
     int rc = run_pipeline(c, (const uint8_t*)d_bytes, (const uint64_t*)d_doc_offsets, n_docs, n_bytes, add_bos,
                           add_eos, s, n_ids);
     if (rc != TK_OK) return rc;
@@ -427,11 +427,10 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
         c->err = "TK_POLICY_KEEP needs tk_ctx_set_special_tokens first";
         return TK_ERR_INVALID_ARG;
     }
-    TK_HIP(c, c->dec_lens.reserve((n_ids + 1) * 4));
-    TK_HIP(c, c->dec_boff.reserve((n_ids + 2) * 8));
+    TK_HIP(c, c->dec_lens.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->dec_offs.reserve((n_docs + 1) * 8));
     TK_HIP(c, c->dec_err.reserve(64));
-    TK_HIP(c, c->block_sums.reserve((n_ids / 2048 + 4) * 8));
+    TK_HIP(c, c->block_sums.reserve((n_docs / 2048 + 4) * 8));
     TkDecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.ids = d_ids;
@@ -439,7 +438,6 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.n_ids = n_ids;
     a.n_docs = n_docs;
     a.lens = (uint32_t*)c->dec_lens.p;
-    a.boff = (const uint64_t*)c->dec_boff.p;
     a.out_offs = (uint64_t*)c->dec_offs.p;
     a.err = (unsigned long long*)c->dec_err.p;
     a.tok_blob = (const uint8_t*)c->t_blob.p;
@@ -451,11 +449,11 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.policy = policy;
     TK_HIP(c, hipMemsetAsync(c->dec_err.p, 0xFF, 24, s));
     TK_HIP(c, hipEventRecord(c->ev[0], s));
-    TK_HIP(c, tk_launch_decode_len(a, s));
-    TK_HIP(c, tk_launch_scan(a.lens, n_ids, (uint64_t*)c->dec_boff.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_decode_doclen(a, s));
+    TK_HIP(c, tk_launch_scan(a.lens, n_docs, (uint64_t*)c->dec_offs.p, (uint64_t*)c->block_sums.p, s));
     uint64_t total = 0;
     unsigned long long err[3] = {~0ull, ~0ull, ~0ull};
-    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_boff.p + n_ids, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
     TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 16, hipMemcpyDeviceToHost, s));
     TK_HIP(c, hipStreamSynchronize(s));
     auto doc_of = [&](uint64_t id_index, uint64_t* out) -> int {
@@ -474,7 +472,7 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.out_bytes = (uint8_t*)c->dec_bytes.p;
     a.run_bits = (uint32_t*)c->dec_bits.p;
     TK_HIP(c, hipMemsetAsync(c->dec_bits.p, 0, (total / 32 + 4) * 4, s));
-    TK_HIP(c, tk_launch_decode_copy(a, s));
+    TK_HIP(c, tk_launch_decode_emit(a, s));
     TK_HIP(c, tk_launch_decode_validate(a, s));
     TK_HIP(c, hipEventRecord(c->ev[2], s));
     TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 24, hipMemcpyDeviceToHost, s));
@@ -540,7 +538,7 @@ extern "C" int tk_decode_batch_device(tk_ctx* c, const void* d_ids, const void* 
     std::lock_guard<std::mutex> lock(c->mu);
     if (!d_id_offsets || (!d_ids && n_ids) || !d_bytes || !d_out_offsets || !n_bytes) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
     TK_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream;  // NULL = HIP's null stream: ordered after the caller's own work on it
     int rc = run_decode(c, (const uint32_t*)d_ids, (const uint64_t*)d_id_offsets, n_docs, n_ids, policy, s, n_bytes, bad_doc);
     if (rc != TK_OK) return rc;
     *d_bytes = c->dec_bytes.p;

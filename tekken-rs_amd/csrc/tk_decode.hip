@@ -7,12 +7,11 @@
 //   (CoreBPE::decode -> String::from_utf8, :552-555); the document text is the join of the runs.
 //
 // GPU formulation (byte/index work, HBM-bound):
-//   tk_decode_len_kernel     one thread per id: byte length of what the id contributes + error flags
-//   (tk_scan_*)              exclusive scan of the lengths -> byte offset of every id (u64)
-//   tk_decode_copy_kernel    one lane per id: token bytes are scattered into an LDS image of the workgroup's
-//                            output span and streamed out with aligned coalesced dword stores; ids that
-//                            start a run mark a bit in a run-start bitmap
-//   tk_decode_docoffs_kernel out_offsets[d] = byte offset of the document's first id
+//   tk_decode_doclen_kernel  one wave per document, one lane per id: text length of the document + error flags
+//   (tk_scan_*)              exclusive scan of the document lengths -> out_offsets (u64)
+//   tk_decode_emit_kernel    one wave per document, 64 ids at a time: in-register prefix sum, token bytes
+//                            scattered into a per-wave LDS image of the chunk's span, streamed out with
+//                            aligned coalesced dword stores; ids that start a run mark a bit in a bitmap
 //   tk_decode_validate_kernel one lane per output byte: UTF-8 well-formedness where run starts and
 //                            document boundaries are hard boundaries (a code point may not span them)
 #include <hip/hip_runtime.h>
@@ -24,77 +23,109 @@
 
 // error word layout: [0] first id index with a Raise-policy special token (or ~0), [1] first id index
 // that is out of the vocabulary, [2] first document with an invalid UTF-8 run
-__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_len_kernel(TkDecodeArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * TKD_BLOCK + threadIdx.x;
-    if (i >= a.n_ids) return;
-    const uint32_t id = a.ids[i];
-    uint32_t len = 0;
+
+// what one id contributes: source pointer + length (0 for ignored / erroneous ids)
+__device__ __forceinline__ uint32_t tkd_piece(const TkDecodeArgs& a, uint32_t id, const uint8_t** src) {
     if (id < a.num_special) {
-        if (a.policy == TK_POLICY_RAISE) atomicMin(a.err + 0, (unsigned long long)i);
-        else if (a.policy == TK_POLICY_KEEP) len = a.sp_offs[id + 1] - a.sp_offs[id];
-    } else {
-        const uint32_t r = id - a.num_special;
-        if (r >= a.n_ranks) atomicMin(a.err + 1, (unsigned long long)i);
-        else len = a.tok_offs[r + 1] - a.tok_offs[r];
+        if (a.policy != TK_POLICY_KEEP) return 0u;
+        *src = a.sp_blob + a.sp_offs[id];
+        return a.sp_offs[id + 1] - a.sp_offs[id];
     }
-    a.lens[i] = len;
+    const uint32_t r = id - a.num_special;
+    if (r >= a.n_ranks) return 0u;
+    *src = a.tok_blob + a.tok_offs[r];
+    return a.tok_offs[r + 1] - a.tok_offs[r];
 }
 
-// One workgroup = 256 consecutive ids = one contiguous span of output bytes (about 1 KB).  Lanes scatter
-// their token bytes into an LDS image of that span (byte writes stay on chip), then the workgroup
-// streams the image to HBM with aligned, fully coalesced dword stores; only the first and last partial
-// dword of the span are written byte-wise (their other bytes belong to the neighbouring workgroups).
-#define TKD_LDS_BYTES 8192u
-__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_copy_kernel(TkDecodeArgs a) {
-    __shared__ uint32_t img[TKD_LDS_BYTES / 4 + 2];
-    const uint64_t i0 = (uint64_t)blockIdx.x * TKD_BLOCK;
-    const uint64_t i = i0 + threadIdx.x;
-    const uint64_t i1 = i0 + TKD_BLOCK < a.n_ids ? i0 + TKD_BLOCK : a.n_ids;
-    const uint64_t base = a.boff[i0], end = a.boff[i1];  // block-uniform
-    const uint8_t* src = nullptr;
-    uint32_t len = 0;
-    uint64_t dst = 0;
-    if (i < a.n_ids) {
-        const uint32_t id = a.ids[i];
-        dst = a.boff[i];
-        const bool special = id < a.num_special;
-        // hard boundary for UTF-8 validation: the first id of every run.  A conservative superset is marked:
-        // every special id and every id that follows a special one (document starts are boundaries anyway).
-        const bool prev_special = i > 0 && a.ids[i - 1] < a.num_special;
-        if (special || prev_special) atomicOr(a.run_bits + (dst >> 5), 1u << (dst & 31));
-        if (special) {
-            if (a.policy == TK_POLICY_KEEP) { src = a.sp_blob + a.sp_offs[id]; len = a.sp_offs[id + 1] - a.sp_offs[id]; }
-        } else {
-            const uint32_t r = id - a.num_special;
-            if (r < a.n_ranks) { src = a.tok_blob + a.tok_offs[r]; len = a.tok_offs[r + 1] - a.tok_offs[r]; }
-        }
-    }
-    const uint64_t g0 = base & ~3ull;  // the image starts at an aligned global address
-    if (end - g0 <= TKD_LDS_BYTES) {
-        uint8_t* img8 = reinterpret_cast<uint8_t*>(img);
-        const uint32_t off = (uint32_t)(dst - g0);
-        for (uint32_t k = 0; k < len; ++k) img8[off + k] = src[k];
-        __syncthreads();
-        const uint32_t nwords = (uint32_t)((end - g0 + 3) / 4);
-        for (uint32_t w = threadIdx.x; w < nwords; w += TKD_BLOCK) {
-            const uint64_t ga = g0 + 4ull * w;
-            if (ga >= base && ga + 4 <= end) {
-                *reinterpret_cast<uint32_t*>(a.out_bytes + ga) = img[w];
-            } else {
-                const uint64_t lo = ga > base ? ga : base, hi = ga + 4 < end ? ga + 4 : end;
-                for (uint64_t q = lo; q < hi; ++q) a.out_bytes[q] = img8[q - g0];
+__device__ __forceinline__ uint32_t tkd_wave_sum(uint32_t v) {
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// pass A: one wave per document, one lane per id: the document's text length + error flags
+__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_doclen_kernel(TkDecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_BLOCK / 64);
+    for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
+        const uint64_t i0 = a.id_offs[d], i1 = a.id_offs[d + 1];
+        uint32_t acc = 0;
+        for (uint64_t i = i0 + (uint64_t)lane; i < i1; i += 64) {
+            const uint32_t id = a.ids[i];
+            if (id < a.num_special) {
+                if (a.policy == TK_POLICY_RAISE) atomicMin(a.err + 0, (unsigned long long)i);
+            } else if (id - a.num_special >= a.n_ranks) {
+                atomicMin(a.err + 1, (unsigned long long)i);
             }
+            const uint8_t* src;
+            acc += tkd_piece(a, id, &src);
         }
-    } else {
-        uint8_t* out = a.out_bytes + dst;  // unusually long tokens: direct byte stores
-        for (uint32_t k = 0; k < len; ++k) out[k] = src[k];
+        acc = tkd_wave_sum(acc);
+        if (lane == 0) a.lens[d] = acc;
     }
 }
 
-__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_docoffs_kernel(TkDecodeArgs a) {
-    const uint64_t d = (uint64_t)blockIdx.x * TKD_BLOCK + threadIdx.x;
-    if (d > a.n_docs) return;
-    a.out_offs[d] = a.boff[a.id_offs[d]];  // boff has n_ids + 1 entries; id_offs[n_docs] == n_ids
+// pass B: one wave per document.  64 ids at a time: an in-register prefix sum places every token inside the
+// chunk's byte span, lanes scatter their token bytes into a per-wave LDS image of that span (byte writes
+// stay on chip), and the wave streams the image to HBM with aligned, coalesced dword stores; only the
+// first / last partial dword of a span is written byte-wise.  ids that start a run mark a bit for the
+// UTF-8 pass.
+#define TKD_IMG_BYTES 4096u
+__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs a) {
+    __shared__ uint32_t img_all[(TKD_BLOCK / 64) * (TKD_IMG_BYTES / 4 + 2)];
+    const int lane = threadIdx.x & 63;
+    uint32_t* img = img_all + (threadIdx.x >> 6) * (TKD_IMG_BYTES / 4 + 2);
+    uint8_t* img8 = reinterpret_cast<uint8_t*>(img);
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_BLOCK / 64);
+    for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
+        const uint64_t i0 = a.id_offs[d], i1 = a.id_offs[d + 1];
+        uint64_t cursor = a.out_offs[d];
+        for (uint64_t c0 = i0; c0 < i1; c0 += 64) {
+            const uint64_t i = c0 + (uint64_t)lane;
+            const uint8_t* src = nullptr;
+            uint32_t len = 0;
+            bool mark = false;
+            if (i < i1) {
+                const uint32_t id = a.ids[i];
+                len = tkd_piece(a, id, &src);
+                // run starts (superset): every special id and every id that follows one
+                mark = id < a.num_special || (i > i0 && a.ids[i - 1] < a.num_special);
+            }
+            uint32_t incl = len;  // inclusive prefix sum over the 64 lanes
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o = __shfl_up(incl, dd);
+                if (lane >= dd) incl += o;
+            }
+            const uint32_t span = __shfl(incl, 63);
+            const uint64_t dst = cursor + (incl - len);
+            if (mark) atomicOr(a.run_bits + (dst >> 5), 1u << (dst & 31));
+            const uint64_t base = cursor, end = cursor + span, g0 = base & ~3ull;
+            if (end - g0 <= TKD_IMG_BYTES) {
+                const uint32_t off = (uint32_t)(dst - g0);
+                for (uint32_t k = 0; k < len; ++k) img8[off + k] = src[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t nwords = (uint32_t)((end - g0 + 3) / 4);
+                for (uint32_t w = (uint32_t)lane; w < nwords; w += 64u) {
+                    const uint64_t ga = g0 + 4ull * w;
+                    if (ga >= base && ga + 4 <= end) {
+                        *reinterpret_cast<uint32_t*>(a.out_bytes + ga) = img[w];
+                    } else {
+                        const uint64_t lo = ga > base ? ga : base, hi = ga + 4 < end ? ga + 4 : end;
+                        for (uint64_t q = lo; q < hi; ++q) a.out_bytes[q] = img8[q - g0];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // image reads done before the next chunk overwrites it
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                uint8_t* out = a.out_bytes + dst;  // unusually long tokens: direct byte stores
+                for (uint32_t k = 0; k < len; ++k) out[k] = src[k];
+            }
+            cursor = end;
+        }
+    }
 }
 
 __device__ __forceinline__ bool tkd_is_boundary(const TkDecodeArgs& a, uint64_t p) {
@@ -144,17 +175,20 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
     }
 }
 
-hipError_t tk_launch_decode_len(const TkDecodeArgs& a, hipStream_t s) {
-    if (a.n_ids == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_decode_len_kernel, dim3((uint32_t)((a.n_ids + TKD_BLOCK - 1) / TKD_BLOCK)), dim3(TKD_BLOCK), 0, s, a);
+static uint32_t tkd_doc_grid(uint64_t n_docs) {
+    uint64_t blocks = (n_docs + (TKD_BLOCK / 64) - 1) / (TKD_BLOCK / 64);
+    return (uint32_t)(blocks > 256 * 16 ? 256 * 16 : blocks);
+}
+
+hipError_t tk_launch_decode_doclen(const TkDecodeArgs& a, hipStream_t s) {
+    if (a.n_docs == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_decode_doclen_kernel, dim3(tkd_doc_grid(a.n_docs)), dim3(TKD_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t tk_launch_decode_copy(const TkDecodeArgs& a, hipStream_t s) {
-    if (a.n_ids) {
-        hipLaunchKernelGGL(tk_decode_copy_kernel, dim3((uint32_t)((a.n_ids + TKD_BLOCK - 1) / TKD_BLOCK)), dim3(TKD_BLOCK), 0, s, a);
-    }
-    hipLaunchKernelGGL(tk_decode_docoffs_kernel, dim3((uint32_t)((a.n_docs + 1 + TKD_BLOCK - 1) / TKD_BLOCK)), dim3(TKD_BLOCK), 0, s, a);
+hipError_t tk_launch_decode_emit(const TkDecodeArgs& a, hipStream_t s) {
+    if (a.n_docs == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_decode_emit_kernel, dim3(tkd_doc_grid(a.n_docs)), dim3(TKD_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

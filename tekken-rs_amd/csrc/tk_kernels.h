@@ -28,10 +28,9 @@ struct TkDecodeArgs {
     const uint32_t* ids;       // [n_ids] packed token ids of all documents
     const uint64_t* id_offs;   // [n_docs + 1]
     uint64_t n_ids, n_docs;
-    uint32_t* lens;            // [n_ids] bytes contributed by every id
-    const uint64_t* boff;      // [n_ids + 1] exclusive scan of lens
+    uint32_t* lens;            // [n_docs] text bytes of every document
     uint8_t* out_bytes;        // [total bytes]
-    uint64_t* out_offs;        // [n_docs + 1]
+    uint64_t* out_offs;        // [n_docs + 1] exclusive scan of lens
     uint32_t* run_bits;        // bitmap over output bytes: 1 = a run starts here (hard UTF-8 boundary)
     unsigned long long* err;   // [3] see tk_decode.hip
     const uint8_t* tok_blob;   // token bytes by rank
@@ -41,8 +40,8 @@ struct TkDecodeArgs {
     uint32_t n_ranks, num_special;
     int policy;                // TK_POLICY_*
 };
-hipError_t tk_launch_decode_len(const TkDecodeArgs& a, hipStream_t s);
-hipError_t tk_launch_decode_copy(const TkDecodeArgs& a, hipStream_t s);      // copy + document offsets
+hipError_t tk_launch_decode_doclen(const TkDecodeArgs& a, hipStream_t s);
+hipError_t tk_launch_decode_emit(const TkDecodeArgs& a, hipStream_t s);
 hipError_t tk_launch_decode_validate(const TkDecodeArgs& a, hipStream_t s);
 
 // max document length over the deferred documents (atomicMax into *d_out, which must be zeroed)

@@ -10,7 +10,8 @@ batch of synthetic documents already resident in HBM:
   N > 1 : configs[3] shape = 1 M x 512-byte documents PER GPU (weak scaling: 8 M over 8 GPUs),
           contiguous shards, plus the single RCCL gather of the id buffers to rank 0 inside the step.
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (tk_encode_kernel<0>) against the HBM roofline:
+  roofline     -- the dominant kernel (tk_flat_kernel: split + lookup + merge, one wave per 1024-byte region)
+                  against the HBM roofline:
                   algorithmic bytes (N_in + 8(D+1) + 4 T_out + 8(D+1)) per launch divided by
                   its mean duration measured live with HIP events on the launch stream
   cpu_baseline -- the CPU oracle (a restatement, "port": the reference is Rust and cannot be built
@@ -147,7 +148,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("tk_encode_kernel_bytes_per_launch")
+                    traffic = json.load(f).get("tk_flat_kernel_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
@@ -161,9 +162,10 @@ def main():
                 "vocab": vocab_kind, "add_bos": True, "add_eos": True, "sharding": "contiguous whole documents per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "tk_encode_kernel<0>", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+                         "kernel": "tk_flat_kernel", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
                          "pipeline_ms": round(float(np.mean(pipe_ms)), 4)},
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
+            "handed_back_docs": eng.last_stats()["handed_back"],
         }
         if not distributed and args.decode_steps > 0:
             out["decode"] = decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream)

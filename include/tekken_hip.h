@@ -120,8 +120,9 @@ int tk_decode_batch_device(tk_ctx* ctx, const void* d_ids, const void* d_id_offs
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
 int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);
 
-/* Counters of the last call: documents handled by the long-piece path, windows processed. */
-int tk_last_stats(const tk_ctx* ctx, uint64_t* n_long_docs, uint64_t* reserved);
+/* Counters of the last call: documents handled by the long-piece path (pass 2), and documents the flat
+ * chunk-per-wave kernel handed back to the per-document kernels (non-ASCII, very long runs / pieces). */
+int tk_last_stats(const tk_ctx* ctx, uint64_t* n_long_docs, uint64_t* n_handed_back);
 
 /* Pre-tokenization split only (vocab-free): out_is_start[i] = 1 iff a piece starts at byte i of
  * the packed buffer (host in / host out).  Debug / parity entry for the split rules. */

@@ -323,7 +323,7 @@ class Engine:
     def last_stats(self):
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
         lib().tk_last_stats(self._h, ctypes.byref(a), ctypes.byref(b))
-        return {"long_docs": int(a.value)}
+        return {"long_docs": int(a.value), "handed_back": int(b.value)}
 
     def split_docs(self, docs):
         """Piece-start offsets per document (vocab-free split, debug / parity entry)."""

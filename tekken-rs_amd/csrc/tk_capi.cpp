@@ -57,6 +57,9 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
+    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo;  // flat path (tk_flat.hip)
+    bool use_flat = true;
+    uint64_t n_flagged = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
     uint64_t n_long_docs = 0;
@@ -147,6 +150,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         c->err = "wave primitive self-test failed on this device (mask " + std::to_string(bad) + ")";
         return fail(TK_ERR_RUNTIME);
     }
+    if (const char* pl = getenv("TK_PIPELINE")) c->use_flat = strcmp(pl, "doc") != 0;  // "doc": per-document kernels only
     *out_ctx = c;
     return TK_OK;
 }
@@ -158,7 +162,8 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
-                      &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg};
+                      &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
+                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -170,8 +175,38 @@ extern "C" const char* tk_last_error(const tk_ctx* c) { return c ? c->err.c_str(
 
 const TkHostTables* tk_ctx_host_tables(const tk_ctx* c) { return c ? &c->host : nullptr; }
 
-// counters layout (u32): [0] work queue head, [1] deferred documents, [2] invalid docs, [3] max deferred length
-static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
+// Pass 2 over the n_def documents of c->defer_list: documents with a long piece that missed the vocabulary need the
+// scratch-backed cooperative merge.  The scratch is sized from the longest deferred document.
+static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_t n_def, hipStream_t s) {
+    const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
+    uint32_t maxlen32 = 0;
+    TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 3, 0, 4, s));
+    TK_HIP(c, tk_launch_defer_maxlen((const uint32_t*)c->defer_list.p, n_def, d_offs, (uint32_t*)c->counters.p + 3, s));
+    TK_HIP(c, hipMemcpyAsync(&maxlen32, (uint32_t*)c->counters.p + 3, 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    const uint64_t maxlen = maxlen32;
+    if (dbg) fprintf(stderr, "[tk] pass2: n_def=%u maxlen=%llu\n", n_def, (unsigned long long)maxlen);
+    const uint64_t words = ((4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;  // 16-byte aligned slices
+    // the grid is launched in blocks of 4 waves and EVERY launched wave owns a scratch slice
+    uint64_t waves2 = n_def < 1024 ? n_def : 1024;
+    const uint64_t budget_words = (8ull << 30) / 4;
+    if (waves2 * words > budget_words) waves2 = budget_words / words;
+    waves2 = ((waves2 + 3) / 4) * 4;
+    if (waves2 == 0) waves2 = 4;
+    TK_HIP(c, c->scratch.reserve(waves2 * words * 4));
+    a.todo_list = (const uint32_t*)c->defer_list.p;
+    a.n_todo = n_def;
+    a.scratch = (uint32_t*)c->scratch.p;
+    a.scratch_words_per_wave = words;
+    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
+    TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
+    if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] pass2 kernel done\n"); }
+    return TK_OK;
+}
+
+// counters layout (u32): [0] work queue head, [1] deferred documents, [2] invalid docs, [3] max deferred length,
+// [4] documents the flat path handed back
+static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
     const uint64_t cap = n_bytes + 2 * n_docs + 64;
     TK_HIP(c, c->staging.reserve(cap * 4));
@@ -222,31 +257,8 @@ static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_off
     const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
     if (dbg) fprintf(stderr, "[tk] pass1 done: docs=%llu deferred=%u total=%llu\n", (unsigned long long)n_docs, ctr[1], (unsigned long long)total);
     if (ctr[1] != 0 && getenv("TK_DEBUG_SKIP_PASS2") == nullptr) {
-        // rare: documents with a long piece that missed the vocabulary need the scratch-backed
-        // cooperative merge.  Size the scratch from the longest deferred document.
-        const uint32_t n_def = ctr[1];
-        uint32_t maxlen32 = 0;
-        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 3, 0, 4, s));
-        TK_HIP(c, tk_launch_defer_maxlen((const uint32_t*)c->defer_list.p, n_def, d_offs, (uint32_t*)c->counters.p + 3, s));
-        TK_HIP(c, hipMemcpyAsync(&maxlen32, (uint32_t*)c->counters.p + 3, 4, hipMemcpyDeviceToHost, s));
-        TK_HIP(c, hipStreamSynchronize(s));
-        const uint64_t maxlen = maxlen32;
-        if (dbg) fprintf(stderr, "[tk] pass2: n_def=%u maxlen=%llu\n", n_def, (unsigned long long)maxlen);
-        const uint64_t words = ((4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;  // 16-byte aligned slices
-        // the grid is launched in blocks of 4 waves and EVERY launched wave owns a scratch slice
-        uint64_t waves2 = n_def < 1024 ? n_def : 1024;
-        const uint64_t budget_words = (8ull << 30) / 4;
-        if (waves2 * words > budget_words) waves2 = budget_words / words;
-        waves2 = ((waves2 + 3) / 4) * 4;
-        if (waves2 == 0) waves2 = 4;
-        TK_HIP(c, c->scratch.reserve(waves2 * words * 4));
-        a.todo_list = (const uint32_t*)c->defer_list.p;
-        a.n_todo = n_def;
-        a.scratch = (uint32_t*)c->scratch.p;
-        a.scratch_words_per_wave = words;
-        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
-        TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
-        if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] pass2 kernel done\n"); }
+        int rc2 = run_pass2(c, a, d_offs, ctr[1], s);
+        if (rc2 != TK_OK) return rc2;
         TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs,
                                     (uint32_t*)c->out_ids.p, s));
@@ -258,6 +270,111 @@ static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_off
     (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[0], c->ev[2]);
     *n_ids = total;
     return TK_OK;
+}
+
+// The flat pipeline (tk_flat.hip): one wave per 1024-byte region of the packed stream, documents the
+// fast path cannot take (non-ASCII, very long runs / pieces) redone by the per-document kernels.
+static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
+                             int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
+    const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
+    const uint64_t n_chunks = (n_bytes + TKF_COMMIT - 1) / TKF_COMMIT;
+    TK_HIP(c, c->f_first.reserve((n_chunks + 1) * 4));
+    TK_HIP(c, c->f_tmp.reserve((n_chunks * TKF_STRIDE + 64) * 4));
+    TK_HIP(c, c->f_k.reserve((n_chunks + 1) * 4));
+    TK_HIP(c, c->f_P.reserve((n_chunks + 2) * 8));
+    TK_HIP(c, c->f_lstart.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->f_flags.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->f_todo.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
+    const uint64_t scan_n = n_docs > n_chunks ? n_docs : n_chunks;
+    TK_HIP(c, c->block_sums.reserve((scan_n / 2048 + 4) * 8));
+
+    TkFlatArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.bytes = d_bytes;
+    fa.doc_offs = d_offs;
+    fa.n_docs = n_docs;
+    fa.n_bytes = n_bytes;
+    fa.n_chunks = n_chunks;
+    fa.first_doc = (const uint32_t*)c->f_first.p;
+    fa.tmp = (uint32_t*)c->f_tmp.p;
+    fa.kcount = (uint32_t*)c->f_k.p;
+    fa.lstart = (uint32_t*)c->f_lstart.p;
+    fa.flags = (uint32_t*)c->f_flags.p;
+    fa.t = c->dview;
+
+    TK_HIP(c, hipEventRecord(c->ev[3], s));
+    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, s));
+    TK_HIP(c, hipMemsetAsync(c->f_flags.p, 0, (n_docs + 1) * 4, s));
+    TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, s));
+    TK_HIP(c, hipEventRecord(c->ev[0], s));
+    TK_HIP(c, tk_launch_flat(fa, s));
+    TK_HIP(c, hipEventRecord(c->ev[1], s));
+    TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
+    TK_HIP(c, tk_launch_scan(fa.kcount, n_chunks, (uint64_t*)c->f_P.p, (uint64_t*)c->block_sums.p, s));
+    uint32_t n_todo = 0;
+    TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    c->n_flagged = n_todo;
+    c->n_long_docs = 0;
+    if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,
+                     (unsigned long long)n_chunks, n_todo);
+    if (n_todo) {
+        // the per-document path over the handed-back documents: pass 1 (mode 3), then pass 2 for its own deferrals
+        TK_HIP(c, c->staging.reserve((n_bytes + 2 * n_docs + 64) * 4));
+        TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
+        TkEncodeArgs a;
+        memset(&a, 0, sizeof(a));
+        a.bytes = d_bytes;
+        a.doc_offs = d_offs;
+        a.n_docs = n_docs;
+        a.staging = (uint32_t*)c->staging.p;
+        a.counts = (uint32_t*)c->counts.p;
+        a.work_counter = (uint32_t*)c->counters.p;
+        a.defer_count = (uint32_t*)c->counters.p + 1;
+        a.defer_list = (uint32_t*)c->defer_list.p;
+        a.todo_list = (const uint32_t*)c->f_todo.p;
+        a.n_todo = n_todo;
+        a.add_bos = add_bos;
+        a.add_eos = add_eos;
+        a.t = c->dview;
+        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
+        const uint64_t want = ((uint64_t)n_todo + 7) / 8;
+        TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), s));
+        uint32_t n_def = 0;
+        TK_HIP(c, hipMemcpyAsync(&n_def, (uint32_t*)c->counters.p + 1, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        c->n_long_docs = n_def;
+        if (n_def) {
+            int rc2 = run_pass2(c, a, d_offs, n_def, s);
+            if (rc2 != TK_OK) return rc2;
+        }
+    }
+    TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, (const uint64_t*)c->f_P.p, fa.lstart, fa.flags,
+                                    (uint32_t)((add_bos ? 1 : 0) + (add_eos ? 1 : 0)), (uint32_t*)c->counts.p, s));
+    TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
+    uint64_t total = 0;
+    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    TK_HIP(c, c->out_ids.reserve((total + 64) * 4));
+    TK_HIP(c, tk_launch_flat_assemble(d_offs, n_docs, n_bytes, n_chunks, (const uint64_t*)c->f_P.p, fa.lstart, fa.flags,
+                                      (const uint32_t*)c->counts.p, (const uint64_t*)c->out_offs.p, fa.tmp,
+                                      (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id, c->host.eos_id,
+                                      add_bos, add_eos, s));
+    TK_HIP(c, hipEventRecord(c->ev[2], s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[3], c->ev[2]);
+    *n_ids = total;
+    return TK_OK;
+}
+
+static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
+                        int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
+    if (c->use_flat) return run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+    c->n_flagged = 0;
+    return run_pipeline_doc(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
 }
 
 extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
@@ -363,7 +480,7 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;
     if (n_long_docs) *n_long_docs = c->n_long_docs;
-    if (reserved) *reserved = 0;
+    if (reserved) *reserved = c->n_flagged;  // documents the flat path handed back to the per-document kernels
     return TK_OK;
 }
 

@@ -772,12 +772,13 @@ TK_DEV void tk_encode_doc_seq(const TkEncodeArgs& a, uint64_t d, int lane, const
 // ------------------------------------------------------------------------------------------
 // one wave: pull documents from the work queue until it is empty
 // ------------------------------------------------------------------------------------------
-// MODE 0: pass 1 over all documents; MODE 1: pass 2 over todo_list; MODE 2: split only
+// MODE 0: pass 1 over all documents; MODE 1: pass 2 over todo_list; MODE 2: split only;
+// MODE 3: pass 1 over todo_list (the documents the flat path, tk_flat_impl.h, handed back)
 template <int MODE>
 TK_DEV void tk_encode_wave(const TkEncodeArgs& a, int lane, uint64_t wave_id) {
     const TkPolyPow pw = tk_poly_pow(a.t, lane);
     uint32_t* scratch = MODE == 1 ? a.scratch + wave_id * a.scratch_words_per_wave : nullptr;
-    const uint64_t total = MODE == 1 ? (uint64_t)a.n_todo : a.n_docs;
+    const uint64_t total = (MODE == 1 || MODE == 3) ? (uint64_t)a.n_todo : a.n_docs;
     const uint32_t chunk = MODE == 1 ? 1u : TK_DOC_CHUNK;
     for (;;) {
         // Every lane takes part in the fetch (the compiler folds it into ONE atomic of 64*chunk and
@@ -792,12 +793,13 @@ TK_DEV void tk_encode_wave(const TkEncodeArgs& a, int lane, uint64_t wave_id) {
             if (MODE == 1) {
                 tk_encode_doc_seq(a, (uint64_t)wv_first(a.todo_list[q]), lane, pw, scratch);
             } else {
-                const bool ok = tk_encode_doc<MODE>(a, q, lane, pw);
+                const uint64_t doc = MODE == 3 ? (uint64_t)wv_first(a.todo_list[q]) : q;
+                const bool ok = tk_encode_doc<(MODE == 3 ? 0 : MODE)>(a, doc, lane, pw);
                 if (!ok && lane == 0) {
                     // pass 1 only: the document has a piece that does not fit a window
-                    a.counts[q] = 0;
+                    a.counts[doc] = 0;
                     const uint32_t slot = wv_atomic_add(a.defer_count, 1u);
-                    a.defer_list[slot] = (uint32_t)q;
+                    a.defer_list[slot] = (uint32_t)doc;
                 }
             }
         }

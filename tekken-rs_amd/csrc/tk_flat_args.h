@@ -1,0 +1,27 @@
+// tk_flat_args.h -- geometry and argument block of the flat path (host + device view), see tk_flat_impl.h.
+#ifndef TK_FLAT_ARGS_H
+#define TK_FLAT_ARGS_H
+#include <stdint.h>
+
+#include "tk_tables.h"
+
+#define TKF_REGION 1024                              /* bytes loaded per chunk: 64 lanes x 16 bytes */
+#define TKF_HL 32                                    /* left halo (look-behind context) */
+#define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
+#define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* 928 bytes committed per chunk */
+#define TKF_STRIDE (TKF_COMMIT + 64)                 /* id slots per chunk: a piece may reach 63 bytes past the commit range */
+
+struct TkFlatArgs {
+    const uint8_t* bytes;        // packed text of all documents
+    const uint64_t* doc_offs;    // [n_docs + 1]
+    uint64_t n_docs, n_bytes, n_chunks;
+    const uint32_t* first_doc;   // [n_chunks] documents that start below the chunk's loaded region
+    uint32_t* tmp;               // [n_chunks * TKF_STRIDE] chunk-dense ids
+    uint32_t* kcount;            // [n_chunks] ids of the chunk
+    uint32_t* lstart;            // [n_docs] ids of the chunk before the document's first byte
+    uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
+    uint8_t* dbg_starts;         // optional: per-byte piece-start flags
+    TkTablesView t;
+};
+
+#endif

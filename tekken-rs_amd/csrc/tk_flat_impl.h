@@ -1,0 +1,549 @@
+// tk_flat_impl.h -- the FLAT tokenization path: one wave per CHUNK of the packed byte stream.
+//
+// Same computation as tk_encode_impl.h (CoreBPE::encode behind reference src/tekkenizer.rs:384-386, pattern
+// literal :123) but laid out for the machine instead of for the document:
+//
+//   * the packed text of ALL documents is cut into regions of 1024 bytes; a wave owns one region at a
+//     time, lane l owns bytes [16 l, 16 l + 16) and holds every class / rule mask as 16 bits of a VGPR
+//     ("lane layout": one VALU instruction = one mask operation over 1024 bytes; shifts borrow from
+//     the neighbour lane with DPP, ripple carries cross lanes through a 64-bit carry look-ahead);
+//   * document boundaries are a mask (DS): look-behind shifts are cut at a document start, look-ahead
+//     shifts at a document end, runs are broken there -- documents never cost a branch;
+//   * piece starts are enumerated into LDS and probed ONE LANE PER PIECE (64 probes per instruction
+//     instead of ~13 with one lane per byte);
+//   * pieces that miss the vocabulary are packed, many per 64-lane window, and merged with the
+//     lane-parallel segmented-min rounds of tk_encode_impl.h (tiktoken's order);
+//   * ids are written chunk-dense (chunk c at tmp[c*TKF_STRIDE ..]), K[c] ids per chunk; the rank of
+//     every document start inside its chunk (lstart) lets tk_flat_assemble cut them into documents.
+//
+// Regions overlap: 32 bytes of left halo (look-behind context), 64 of right halo (look-ahead, piece
+// ends), 928 committed.  The fast path is ASCII; a document with a byte >= 0x80, with a digit / CR-LF
+// run that covers the whole left halo, a white-space run that reaches the end of the region, a piece
+// of more than 64 bytes, or in a chunk with more than TKF_MAXMISS missed pieces is flagged and redone
+// by the per-document kernel (tk_encode_impl.h), which handles everything.
+//
+// The rules are modelled in tools/flat_split_model.py (Python ints as masks, checked against the
+// oracle); this file is that model in lane layout.  Runs on the CPU wave emulator (tests/emu).
+#ifndef TK_FLAT_IMPL_H
+#define TK_FLAT_IMPL_H
+#include <stdint.h>
+
+#include "tk_encode_impl.h"
+#include "tk_flat_args.h"
+
+#define TKF_W 16
+#define TKF_WM 0xFFFFu
+#define TKF_MAXMISS 256
+#define TKF_MISS 0xFFFFFFFEu
+#define TKF_MAXBATCH ((TKF_REGION + 63) / 64 + 1)
+
+// LDS words of one wave
+#define TKF_L_LIST 0                                /* [REGION + 2] piece positions, then parked ranks */
+#define TKF_L_DS (TKF_L_LIST + TKF_REGION + 2)      /* [64] document-start mask words */
+#define TKF_L_PS (TKF_L_DS + 64)                    /* [64] owned piece-start mask words */
+#define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
+#define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
+#define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
+#define TKF_L_MREC (TKF_L_BPFX + 64)                /* [MAXMISS] pos | len << 16 */
+#define TKF_L_MIDX (TKF_L_MREC + TKF_MAXMISS)       /* [MAXMISS] piece index */
+#define TKF_L_CUMX (TKF_L_MIDX + TKF_MAXMISS)       /* [MAXMISS] extra ids up to and including this miss */
+#define TKF_L_MARK (TKF_L_CUMX + TKF_MAXMISS)       /* [64] packed-window piece starts */
+#define TKF_L_MB (TKF_L_MARK + 64)                  /* [3 * MAXBATCH] miss ballot lo, hi, misses before the batch */
+#define TKF_LDS_WORDS (TKF_L_MB + 3 * TKF_MAXBATCH)
+
+
+// ------------------------------------------------------------------------------------------
+// lane-layout mask primitives (16 bits per lane, bit i of lane l = region byte 16 l + i)
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return ((x << k) | (wv_dn1(x) >> (TKF_W - k))) & TKF_WM; }  // 1 <= k <= 16
+TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return ((x >> k) | (wv_up1(x) << (TKF_W - k))) & TKF_WM; }
+TK_DEV uint32_t tkf_shl_any(uint32_t x, int k, int lane) {
+    const int q = k >> 4, r = k & 15;
+    const int s1 = lane - q, s2 = lane - q - 1;
+    uint32_t v1 = wv_shfl(x, s1 & 63), v2 = wv_shfl(x, s2 & 63);
+    if (s1 < 0) v1 = 0;
+    if (s2 < 0) v2 = 0;
+    return ((v1 << r) | (v2 >> (TKF_W - r))) & TKF_WM;
+}
+TK_DEV uint32_t tkf_shr_any(uint32_t x, int k, int lane) {
+    const int q = k >> 4, r = k & 15;
+    const int s1 = lane + q, s2 = lane + q + 1;
+    uint32_t v1 = wv_shfl(x, s1 & 63), v2 = wv_shfl(x, s2 & 63);
+    if (s1 > 63) v1 = 0;
+    if (s2 > 63) v2 = 0;
+    return ((v1 >> r) | (v2 << (TKF_W - r))) & TKF_WM;
+}
+TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
+
+// bits of `run` covered by a carry that starts at `seeds` (subset of run) and ripples upwards through
+// consecutive run bits, across lanes: per-lane add + 64-bit carry look-ahead over the lane carries
+TK_DEV uint32_t tkf_ripple(uint32_t run, uint32_t seeds) {
+    const uint32_t t = run + seeds;
+    const uint64_t G = wv_ballot((t >> TKF_W) != 0u);
+    const uint64_t P = wv_ballot(run == TKF_WM);
+    const uint64_t x = G | P;
+    const uint64_t cin = (x + G) ^ x ^ G;  // carry into lane l = bit l
+    const uint32_t r = (t + (wv_inverse_ballot(cin) ? 1u : 0u)) & TKF_WM;
+    return (r ^ run) & run;
+}
+
+TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = wv_shfl(x, lane >= d ? lane - d : lane);
+        if (lane >= d) x += o;
+    }
+    *total = wv_shfl(x, 63);
+    return x - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// SWAR classification of 16 ASCII bytes per lane -> 16-bit masks
+// ------------------------------------------------------------------------------------------
+struct TkfClass {
+    uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
+};
+
+// flags at bit 7 of every byte of y[0..3] (y[j] byte k = text byte 4k + j) -> 16-bit mask, bit 4k + j
+TK_DEV uint32_t tkf_gather(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    uint32_t c = ((f3 & 0x80808080u) | ((f2 >> 1) & 0x40404040u) | ((f1 >> 2) & 0x20202020u) | ((f0 >> 3) & 0x10101010u)) >> 4;
+    c = (c | (c >> 4)) & 0x00FF00FFu;
+    return (c | (c >> 8)) & 0xFFFFu;
+}
+
+// per byte (all < 0x80 after masking): bit 7 set iff lo <= b <= hi
+TK_DEV uint32_t tkf_range(uint32_t x7, uint32_t lo, uint32_t hi) {
+    const uint32_t ge = x7 + (0x80u - lo) * 0x01010101u;         // b + 0x80 - lo: bit 7 iff b >= lo
+    const uint32_t gt = x7 + (0x7Fu - hi) * 0x01010101u;         // b + 0x7F - hi: bit 7 iff b > hi
+    return ge & ~gt;
+}
+TK_DEV uint32_t tkf_eq(uint32_t x7, uint32_t v) {                // bit 7 set iff b == v
+    const uint32_t y = x7 ^ (v * 0x01010101u);
+    return ~(y + 0x7F7F7F7Fu);
+}
+
+TK_DEV TkfClass tkf_classify(const uint32_t* x) {
+    // 4x4 byte transpose: y[j] = (byte j of x0, x1, x2, x3)
+    const uint32_t a0 = wv_perm(x[1], x[0], 0x05010400u), a1 = wv_perm(x[1], x[0], 0x07030602u);
+    const uint32_t a2 = wv_perm(x[3], x[2], 0x05010400u), a3 = wv_perm(x[3], x[2], 0x07030602u);
+    uint32_t y[4];
+    y[0] = wv_perm(a2, a0, 0x05040100u); y[1] = wv_perm(a2, a0, 0x07060302u);
+    y[2] = wv_perm(a3, a1, 0x05040100u); y[3] = wv_perm(a3, a1, 0x07060302u);
+    uint32_t fL[4], fN[4], fS[4], fNL[4], fSP[4], fAP[4], fHI[4], fSTMD[4], fRV[4], fE[4], fLL[4];
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t hi = y[j] & 0x80808080u, nhi = ~hi;
+        const uint32_t x7 = y[j] & 0x7F7F7F7Fu, f = x7 | 0x20202020u;
+        fHI[j] = hi;
+        fL[j] = tkf_range(f, 0x61u, 0x7Au) & nhi;
+        fN[j] = tkf_range(x7, 0x30u, 0x39u) & nhi;
+        fSP[j] = tkf_eq(x7, 0x20u) & nhi;
+        fS[j] = (tkf_range(x7, 9u, 13u) & nhi) | fSP[j];
+        fNL[j] = (tkf_eq(x7, 10u) | tkf_eq(x7, 13u)) & nhi;
+        fAP[j] = tkf_eq(x7, 0x27u) & nhi;
+        fSTMD[j] = (tkf_range(f, 0x73u, 0x74u) | tkf_eq(f, 0x6Du) | tkf_eq(f, 0x64u)) & nhi;
+        fRV[j] = (tkf_eq(f, 0x72u) | tkf_eq(f, 0x76u)) & nhi;
+        fE[j] = tkf_eq(f, 0x65u) & nhi;
+        fLL[j] = tkf_eq(f, 0x6Cu) & nhi;
+    }
+    TkfClass c;
+    c.L = tkf_gather(fL[0], fL[1], fL[2], fL[3]);
+    c.N = tkf_gather(fN[0], fN[1], fN[2], fN[3]);
+    c.S = tkf_gather(fS[0], fS[1], fS[2], fS[3]);
+    c.NL = tkf_gather(fNL[0], fNL[1], fNL[2], fNL[3]);
+    c.SP = tkf_gather(fSP[0], fSP[1], fSP[2], fSP[3]);
+    c.AP = tkf_gather(fAP[0], fAP[1], fAP[2], fAP[3]);
+    c.HI = tkf_gather(fHI[0], fHI[1], fHI[2], fHI[3]);
+    c.STMD = tkf_gather(fSTMD[0], fSTMD[1], fSTMD[2], fSTMD[3]);
+    c.RV = tkf_gather(fRV[0], fRV[1], fRV[2], fRV[3]);
+    c.E = tkf_gather(fE[0], fE[1], fE[2], fE[3]);
+    c.LL = tkf_gather(fLL[0], fLL[1], fLL[2], fLL[3]);
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// piece starts of the region (tools/flat_split_model.py flat_rules); also returns SPR / cont for the
+// deferral test of the white-space run that reaches the region end
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SPR_out, uint32_t* cont_out) {
+    const uint32_t nDS = ~DS & TKF_WM;
+    const uint32_t DE = tkf_shr(DS, 1) | (lane == 63 ? 0x8000u : 0u);
+    const uint32_t nDE = ~DE & TKF_WM;
+#define P1(x) (tkf_shl((x), 1) & nDS)
+#define N1(x) (tkf_shr((x), 1) & nDE)
+    const uint32_t mL = m.L, mN = m.N, mS = m.S, NL = m.NL, SP = m.SP;
+    const uint32_t mO = TKF_WM & ~(mL | mN | mS);
+    const uint32_t pOS = P1(mO | SP);            // previous byte is class O or U+0020
+    uint32_t CEND = 0;
+    if (tkf_any(m.AP)) {                         // alt 1: fires only where a match starts at the apostrophe
+        const uint32_t ok = m.AP & ~pOS;
+        const uint32_t c2 = ok & N1(m.STMD);
+        const uint32_t c3 = ok & ~c2 & N1((m.RV & N1(m.E)) | (m.LL & N1(m.LL)));
+        CEND = tkf_shl(c2, 2) | tkf_shl(c3, 3);
+    }
+    const uint32_t L1 = P1(mL), O1 = P1(mO);
+    const uint32_t Lst = mL & ~L1;
+    const uint32_t psL = (mL & L1 & CEND) | (Lst & P1(mN | NL)) | (Lst & O1 & P1(pOS));
+    const uint32_t psO = mO & ~O1 & ~P1(SP);
+    // numbers: every 3rd char of a run (\p{N}{1,3}), prefix doubling
+    const uint32_t N1m = P1(mN);
+    uint32_t psN = mN & ~N1m;
+    {
+        const uint32_t N2m = P1(N1m);
+        uint32_t M = mN & N1m & N2m & P1(N2m);
+        int k = 3;
+        while (tkf_any(M)) {
+            psN |= tkf_shl_any(psN, k, lane) & M;
+            M &= tkf_shl_any(M, k, lane);
+            k *= 2;
+        }
+    }
+    // white space
+    const uint32_t seeds = NL & O1;
+    uint32_t ABS = 0;
+    if (tkf_any(seeds)) ABS = tkf_ripple(NL & nDS, seeds);
+    const uint32_t SPR = mS & ~ABS;
+    const uint32_t cont = SPR & P1(SPR);
+    uint32_t Z = NL & SPR;
+    {
+        uint32_t C = tkf_shr(cont, 1);
+        int k = 1;
+        while (tkf_any(C) && tkf_any(Z)) {
+            Z |= tkf_shr_any(Z, k, lane) & C;
+            C &= tkf_shr_any(C, k, lane);
+            k *= 2;
+        }
+    }
+    const uint32_t psS = (SPR & ~cont) | (tkf_shl(Z, 1) & cont & ~Z) | (SPR & ~tkf_shr(cont, 1) & ~Z & nDE);
+#undef P1
+#undef N1
+    *SPR_out = SPR;
+    *cont_out = cont;
+    return psL | psN | psO | psS | DS;
+}
+
+// ------------------------------------------------------------------------------------------
+// one chunk
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+
+TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds, const TkPolyPow& pw) {
+    (void)pw;
+    const TkTablesView& t = a.t;
+    const int64_t n = (int64_t)a.n_bytes;
+    const int64_t c0 = (int64_t)c * TKF_COMMIT, r0 = c0 - TKF_HL, r1 = r0 + TKF_REGION;
+    const int64_t c1 = c0 + TKF_COMMIT < n ? c0 + TKF_COMMIT : n;
+    const int ca = TKF_HL, cb = (int)(c1 - r0);  // commit range in region coordinates
+    uint32_t* list = lds + TKF_L_LIST;
+
+    // ---- 1. load 16 bytes per lane, classify ---------------------------------------------------
+    uint32_t x[4] = {0u, 0u, 0u, 0u};
+    {
+        const int64_t g = r0 + 16 * lane;
+        if (g >= 0 && g + 16 <= n) {
+            wv_load16(a.bytes + g, x);
+        } else if (g + 16 > 0 && g < n) {
+            for (int k = 0; k < 16; ++k) {
+                const int64_t q = g + k;
+                if (q >= 0 && q < n) x[k >> 2] |= (uint32_t)a.bytes[q] << (8 * (k & 3));
+            }
+        }
+    }
+    const TkfClass m = tkf_classify(x);
+
+    // ---- 2. document starts inside the region -> DS (lane layout, through LDS) ------------------
+    lds[TKF_L_DS + lane] = 0u;
+    lds[TKF_L_BAD + lane] = 0u;
+    wv_lds_sync();
+    const uint64_t fd = a.first_doc[c];          // documents that start below max(r0, 0)
+    bool starts_at_r1 = false;
+    {
+        // documents d >= fd start at or above the region start; d == n_docs stands for the end of the stream
+        for (uint64_t base = fd;; base += 64) {
+            const uint64_t d = base + (uint64_t)lane;
+            int64_t s = INT64_MAX;
+            if (d <= a.n_docs) s = (int64_t)a.doc_offs[d];
+            const bool in = s < r1;
+            if (in) wv_lds_or(lds + TKF_L_DS + ((s - r0) >> 4), 1u << ((s - r0) & 15));
+            if (s == r1) starts_at_r1 = true;
+            if (wv_ballot(in) != ~0ull) break;
+        }
+        starts_at_r1 = wv_ballot(starts_at_r1) != 0ull;
+    }
+    wv_lds_sync();
+    const uint32_t DS = lds[TKF_L_DS + lane];
+
+    // ---- 3. piece starts ---------------------------------------------------------------------------
+    uint32_t SPR, cont;
+    const uint32_t PS = tkf_rules(m, DS, lane, &SPR, &cont);
+    const uint32_t commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
+    if (a.dbg_starts) {
+        for (int k = 0; k < 16; ++k)
+            if ((commit_mask >> k) & 1u) a.dbg_starts[r0 + 16 * lane + k] = (PS >> k) & 1u;
+    }
+
+    // ---- 4. positions that make their document fall back ---------------------------------------
+    uint32_t BAD = m.HI & commit_mask;
+    {
+        // (A) a digit / CR-LF run that comes from below the region and covers the whole left halo
+        const uint32_t d0 = wv_readlane(DS, 0), d1 = wv_readlane(DS, 1);
+        const uint32_t n0 = wv_readlane(m.N, 0), n1 = wv_readlane(m.N, 1);
+        const uint32_t l0 = wv_readlane(m.NL, 0), l1 = wv_readlane(m.NL, 1);
+        const bool covered = (n0 == TKF_WM && n1 == TKF_WM) || (l0 == TKF_WM && l1 == TKF_WM);
+        if (r0 > 0 && d0 == 0u && d1 == 0u && covered && lane == 2) BAD |= 1u;
+        // (B) a white-space run that reaches the region end, goes on in the same document and started inside
+        //     the commit range
+        const uint32_t top = wv_readlane(SPR, 63);
+        if (r1 < n && (top & 0x8000u) && !starts_at_r1) {
+            const uint32_t nz = ~cont & TKF_WM;
+            const uint64_t NZ = wv_ballot(nz != 0u);
+            int f = 0;
+            if (NZ) {
+                const int tl = tk_msb64(NZ);
+                const uint32_t w = wv_readlane(nz, tl);
+                f = 16 * tl + (31 - __builtin_clz(w));
+            }
+            if (f < cb) {
+                const int at = f > ca ? f : ca;
+                if (lane == (at >> 4)) BAD |= 1u << (at & 15);
+            }
+        }
+    }
+
+    // ---- 5. enumerate the pieces: positions of the set bits of PS from the commit start on -------
+    const uint32_t PSown = PS & commit_mask;
+    const uint32_t PSlist = lane >= 2 ? PS : 0u;            // commit range and right halo (ends of the last pieces)
+    uint32_t np_all, np_own;
+    const uint32_t pfx_all = tkf_scan_excl((uint32_t)__builtin_popcount(PSlist), lane, &np_all);
+    const uint32_t pfx_own = tkf_scan_excl((uint32_t)__builtin_popcount(PSown), lane, &np_own);
+    {
+        uint32_t w = PSlist, idx = pfx_all;
+        while (wv_ballot(w != 0u)) {
+            if (w) {
+                list[idx++] = (uint32_t)(16 * lane + __builtin_ctz(w));
+                w &= w - 1u;
+            }
+        }
+        if (lane == 0) list[np_all] = TKF_REGION;           // sentinel: the region end
+    }
+    lds[TKF_L_PS + lane] = PSown;
+    lds[TKF_L_PFX + lane] = pfx_own;
+    wv_lds_sync();
+
+    // ---- 6. whole-piece lookup, one lane per piece ---------------------------------------------------
+    const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
+    uint32_t nmiss = 0;
+    bool overflow = false;
+    const uint32_t nbatch = (np_own + 63u) / 64u;
+    for (uint32_t j = 0; j < nbatch; ++j) {
+        const uint32_t idx = j * 64u + (uint32_t)lane;
+        const bool act = idx < np_own;
+        uint32_t pos = 0, len = 1;
+        if (act) {
+            pos = list[idx];
+            len = list[idx + 1] - pos;
+        }
+        uint32_t r = 0;
+        bool toolong = false;
+        if (act) {
+            if (len > 64u) {
+                toolong = true;
+            } else if (len == 1u) {
+                r = rbytes[pos];                            // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
+            } else if (len <= 16u) {
+                uint32_t kk[4] = {0u, 0u, 0u, 0u};
+                const int64_t g = r0 + (int64_t)pos;
+                if (g + 16 <= n) {
+                    wv_load16(a.bytes + g, kk);
+                } else {
+                    for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)rbytes[pos + q] << (8 * (q & 3));
+                }
+                // zero the bytes past the piece
+                for (int q = 0; q < 4; ++q) {
+                    const int keep = (int)len - 4 * q;
+                    kk[q] = keep >= 4 ? kk[q] : keep <= 0 ? 0u : (kk[q] & ((1u << (8 * keep)) - 1u));
+                }
+                r = tk_probe_key(t, kk[0], kk[1], kk[2], kk[3], len);
+            } else {
+                uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
+                for (uint32_t q = 0; q < len; ++q) {
+                    const uint32_t b = rbytes[pos + q];
+                    h1 = h1 * TK_POLY_P1 + b;
+                    h2 = h2 * TK_POLY_P2 + b;
+                }
+                r = tk_probe_long(t, h1, h2, len, rbytes + pos);
+            }
+        }
+        if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> 4), 1u << (pos & 15));
+        const bool miss = act && !toolong && r == TK_RANK_MAX;
+        const uint64_t MB = wv_ballot(miss);
+        if (lane == 0) {
+            lds[TKF_L_MB + 3 * j] = (uint32_t)MB;
+            lds[TKF_L_MB + 3 * j + 1] = (uint32_t)(MB >> 32);
+            lds[TKF_L_MB + 3 * j + 2] = nmiss;
+        }
+        if (miss) {
+            const uint32_t slot = nmiss + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
+            if (slot < TKF_MAXMISS) {
+                lds[TKF_L_MREC + slot] = pos | (len << 16);
+                lds[TKF_L_MIDX + slot] = idx;
+            }
+        }
+        nmiss += (uint32_t)tk_popc64(MB);
+        wv_lds_sync();                                      // positions read before they are overwritten
+        if (act) list[idx] = miss ? TKF_MISS : (toolong ? 0u : r);
+    }
+    if (nmiss > TKF_MAXMISS) {
+        overflow = true;
+        nmiss = 0;
+        BAD |= commit_mask;
+    }
+    wv_lds_sync();
+
+    // ---- 7. merge the pieces that missed: many pieces per 64-lane window ----------------------------
+    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
+    uint32_t E = 0;                                         // extra ids (beyond one per piece) so far
+    for (uint32_t cur = 0; cur < nmiss;) {
+        const uint32_t mi_me = cur + (uint32_t)lane;
+        const uint32_t rec = mi_me < nmiss ? lds[TKF_L_MREC + mi_me] : 0u;
+        const uint32_t pidx_me = mi_me < nmiss ? lds[TKF_L_MIDX + mi_me] : 0u;
+        const uint32_t mylen = mi_me < nmiss ? (rec >> 16) : 1000u;
+        uint32_t incl = mylen;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = wv_shfl(incl, lane >= d ? lane - d : lane);
+            if (lane >= d) incl += o;
+        }
+        const uint64_t TAKE = wv_ballot(incl <= 64u);       // a prefix of the lanes; never empty (len <= 64)
+        const int ntake = tk_popc64(TAKE);
+        const uint32_t total = wv_shfl(incl, ntake - 1);
+        lds[TKF_L_MARK + lane] = 0u;
+        wv_lds_sync();
+        if (lane < ntake) lds[TKF_L_MARK + (incl - mylen)] = (uint32_t)lane + 1u;
+        wv_lds_sync();
+        const uint32_t mark = lds[TKF_L_MARK + lane];
+        const uint64_t Sm = wv_ballot(mark != 0u);          // piece starts of the packed window
+        const int ps = tk_msb64(Sm & tk_lowmask(lane + 1));
+        const int mi = (int)wv_shfl(mark, ps) - 1;          // which taken piece this lane belongs to
+        const uint32_t prec = wv_shfl(rec, mi & 63);
+        const uint32_t pidx = wv_shfl(pidx_me, mi & 63);
+        const bool inmiss = (uint32_t)lane < total;
+        const uint32_t ppos = prec & 0xFFFFu, plen = prec >> 16;
+        const int pe = ps + (int)plen;
+        const uint32_t b0 = inmiss ? (uint32_t)rbytes[ppos + (uint32_t)(lane - ps)] : 0u;
+        const uint32_t b1 = wv_up1(b0);
+        // (the rounds of tk_encode_impl.h step 5: one merge per piece per round, leftmost minimum rank)
+        uint64_t A = wv_ballot(inmiss);
+        uint32_t tok = b0;
+        uint32_t prank = TK_RANK_MAX;
+        if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
+        const int sl = pe - 1 < 63 ? pe - 1 : 63;
+        for (int round = 0; round < 64; ++round) {
+            const uint32_t key = prank == TK_RANK_MAX ? 0xFFFFFFFFu : ((prank << 6) | (uint32_t)lane);
+            uint32_t mn = key;
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o = wv_shfl(mn, lane >= dd ? lane - dd : lane);
+                if (lane >= dd && lane - dd >= ps) mn = o < mn ? o : mn;
+            }
+            const uint32_t segmin = wv_shfl(mn, sl);
+            const bool winner = inmiss && key != 0xFFFFFFFFu && key == segmin;
+            const uint64_t Wm = wv_ballot(winner);
+            if (!Wm) break;
+            const bool alive = tk_bit(A, lane);
+            const uint64_t below = A & tk_lowmask(lane);
+            const bool dead = alive && below && tk_bit(Wm, tk_msb64(below));
+            const uint64_t Dm = wv_ballot(dead);
+            A &= ~Dm;
+            if (winner) tok = prank;
+            if (dead) prank = TK_RANK_MAX;
+            const uint64_t z = lane < 63 ? (A >> (lane + 1)) : 0ull;
+            const int na = z ? lane + 1 + tk_ctz64(z) : 64;
+            const bool has_next = na < pe;
+            const uint32_t tn = wv_shfl(tok, na < 64 ? na : lane);
+            const bool need = tk_bit(A, lane) && (winner || (has_next && tk_bit(Wm, na)));
+            if (need) prank = has_next ? tk_probe_pair(t, tok, tn) : TK_RANK_MAX;
+        }
+        const uint64_t SUB = A & ~Sm;                       // surviving parts that are not piece heads
+        if (inmiss && tk_bit(A, lane))
+            tmp[pidx + E + (uint32_t)tk_popc64(SUB & tk_lowmask(lane + 1))] = tok + t.num_special;
+        if (inmiss && lane == ps) lds[TKF_L_CUMX + cur + (uint32_t)mi] = E + (uint32_t)tk_popc64(SUB & tk_lowmask(pe));
+        E += (uint32_t)tk_popc64(SUB);
+        cur += (uint32_t)ntake;
+    }
+    wv_lds_sync();
+
+    // ---- 8. emit the hits: id slot = piece index + extra ids of the misses before it ----------------
+    for (uint32_t j = 0; j < nbatch; ++j) {
+        const uint32_t idx = j * 64u + (uint32_t)lane;
+        if (idx < np_own) {
+            const uint32_t tv = list[idx];
+            if (tv != TKF_MISS) {
+                uint32_t extra = 0;
+                if (nmiss) {
+                    const uint64_t MB = ((uint64_t)lds[TKF_L_MB + 3 * j + 1] << 32) | lds[TKF_L_MB + 3 * j];
+                    const uint32_t nm = lds[TKF_L_MB + 3 * j + 2] + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
+                    if (nm) extra = lds[TKF_L_CUMX + nm - 1];
+                }
+                tmp[idx + extra] = tv + t.num_special;
+            }
+        }
+    }
+    if (lane == 0) a.kcount[c] = np_own + E;
+
+    // ---- 9. per-document outputs: rank of every document start, fall-back flags ---------------------
+    BAD |= lds[TKF_L_BAD + lane];                           // piece-level marks of step 6
+    const bool anybad = tkf_any(BAD);
+    if (anybad) {
+        uint32_t nb;
+        const uint32_t bp = tkf_scan_excl((uint32_t)__builtin_popcount(BAD), lane, &nb);
+        lds[TKF_L_BAD + lane] = BAD;
+        lds[TKF_L_BPFX + lane] = bp;
+        wv_lds_sync();
+    }
+    (void)overflow;
+    {
+        // documents that touch the commit range: fd - 1 (the one that contains the region start) onwards
+        const uint64_t dfirst = fd > 0 ? fd - 1 : 0;
+        for (uint64_t base = dfirst;; base += 64) {
+            const uint64_t d = base + (uint64_t)lane;
+            int64_t s = INT64_MAX, e = INT64_MAX;
+            if (d < a.n_docs) {
+                s = (int64_t)a.doc_offs[d];
+                e = (int64_t)a.doc_offs[d + 1];
+            }
+            const bool in = s < c1;
+            if (in && s >= c0) {
+                // ids of this chunk before the document's first byte
+                const uint32_t p = (uint32_t)(s - r0);
+                const uint32_t pi = lds[TKF_L_PFX + (p >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_PS + (p >> 4)] & ((1u << (p & 15)) - 1u));
+                uint32_t extra = 0;
+                if (nmiss) {
+                    const uint32_t jb = pi >> 6, q = pi & 63u;
+                    uint32_t nm;
+                    if (jb < nbatch) {
+                        const uint64_t MB = ((uint64_t)lds[TKF_L_MB + 3 * jb + 1] << 32) | lds[TKF_L_MB + 3 * jb];
+                        nm = lds[TKF_L_MB + 3 * jb + 2] + (uint32_t)tk_popc64(MB & tk_lowmask((int)q));
+                    } else {
+                        nm = nmiss;
+                    }
+                    if (nm) extra = lds[TKF_L_CUMX + nm - 1];
+                }
+                a.lstart[d] = pi + extra;
+            }
+            if (anybad && in && e > c0) {
+                // any bad position inside [s, e) clipped to the region?
+                const int64_t lo = s > r0 ? s - r0 : 0, hi = e < r1 ? e - r0 : TKF_REGION;
+                if (hi > lo) {
+                    const uint32_t pl = (uint32_t)lo, ph = (uint32_t)hi;
+                    const uint32_t cl = lds[TKF_L_BPFX + (pl >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (pl >> 4)] & ((1u << (pl & 15)) - 1u));
+                    uint32_t ch;
+                    if (ph >= TKF_REGION) ch = lds[TKF_L_BPFX + 63] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + 63]);
+                    else ch = lds[TKF_L_BPFX + (ph >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (ph >> 4)] & ((1u << (ph & 15)) - 1u));
+                    if (ch > cl) a.flags[d] = 1u;
+                }
+            }
+            if (wv_ballot(in) != ~0ull) break;
+        }
+    }
+    wv_lds_sync();  // the next chunk reuses the LDS slice
+}
+
+#endif

@@ -6,9 +6,10 @@
 
 #include "../../include/tekken_hip.h"
 #include "tk_encode_impl_args.h"
+#include "tk_flat_args.h"
 
 // mode 0: pass 1; mode 1: pass 2 (scratch-backed, every launched wave owns a scratch slice);
-// mode 2: split only.  n_waves = waves launched (rounded up to whole 4-wave blocks)
+// mode 2: split only; mode 3: pass 1 over args.todo_list.  n_waves = waves launched (rounded up to whole 4-wave blocks)
 hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves, hipStream_t s);
 
 // counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
@@ -22,6 +23,19 @@ hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, 
 // UTF-8 validation of every document; *d_bad receives the number of invalid documents
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s);
+
+// ---- flat path (tk_flat.hip, tk_flat_impl.h): one wave per 1024-byte region of the packed stream ----
+hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
+                                   hipStream_t s);
+hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
+hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
+hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
+                                 const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, uint32_t extra,
+                                 uint32_t* counts, hipStream_t s);
+hipError_t tk_launch_flat_assemble(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
+                                   const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* counts,
+                                   const uint64_t* out_offs, const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids,
+                                   uint32_t bos_id, uint32_t eos_id, int add_bos, int add_eos, hipStream_t s);
 
 // ---- decode path (tk_decode.hip) ----
 struct TkDecodeArgs {

@@ -3,6 +3,7 @@
 //   tk_encode_kernel<0>       pass 1: every document, one wave per document at a time
 //   tk_encode_kernel<1>       pass 2: the few documents with a piece that does not fit a window
 //   tk_encode_kernel<2>       split only (tk_split_batch)
+//   tk_encode_kernel<3>       pass 1 over a list of documents (those the flat path handed back)
 //   tk_scan_*                 per-document id counts -> output offsets (exclusive scan, u64)
 //   tk_compact_kernel         staging -> packed ids (the reference's Vec<u32> per document,
 //                             concatenated; ids already carry +num_special and BOS/EOS:
@@ -32,6 +33,7 @@ hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves
     if (blocks == 0) return hipSuccess;
     if (mode == 1) hipLaunchKernelGGL(tk_encode_kernel<1>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
     else if (mode == 2) hipLaunchKernelGGL(tk_encode_kernel<2>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
+    else if (mode == 3) hipLaunchKernelGGL(tk_encode_kernel<3>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
     else hipLaunchKernelGGL(tk_encode_kernel<0>, dim3(blocks), dim3(TK_BLOCK), 0, s, args);
     return hipGetLastError();
 }

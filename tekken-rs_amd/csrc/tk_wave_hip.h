@@ -62,4 +62,26 @@ TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v);
 // executed by ALL 64 lanes in uniform control flow: *p += 64*v, lane i receives old + i*v
 TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
+// ---- primitives of the flat (chunk-per-wave) path, tk_flat_impl.h ----
+// lane-predicate from a wave-uniform 64-bit mask (v_cndmask with the SGPR pair as the condition)
+TK_DEV bool wv_inverse_ballot(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// v_perm_b32: result byte i = byte sel[i] of the 8 bytes {hi:lo} (0..3 = lo, 4..7 = hi)
+TK_DEV uint32_t wv_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// this wave's LDS slice: earlier ds writes of any lane are visible to later ds reads of every lane
+TK_DEV void wv_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// 16 text bytes at p (any alignment) as 4 little-endian dwords
+TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) {
+    typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_u;
+    const u32x4_u v = *reinterpret_cast<const u32x4_u*>(p);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+
 #endif

@@ -22,6 +22,10 @@ def lib():
                                        u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p,
                                        u64p, u8p, u64p, u64p]
         L.emu_last_error.restype = ctypes.c_char_p
+        L.emu_flat_encode_batch.restype = ctypes.c_int
+        L.emu_flat_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                            u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, u64p, u8p, u8p,
+                                            u64p, u64p]
         _LIB = L
     return _LIB
 
@@ -62,3 +66,31 @@ def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos
         a, b = int(offs[d]), int(offs[d + 1])
         starts.append([i for i in range(b - a) if dbg[a + i]])
     return ids, starts, int(ndef.value)
+
+
+def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True):
+    """The flat path (tk_flat_impl.h) on the emulator.  Returns (id lists, starts per document, flagged list)."""
+    toffs = np.zeros(len(token_bytes) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
+    data, offs = pack_docs(docs)
+    n = int(offs[-1])
+    D = len(docs)
+    out = np.zeros(n + 2 * D + 1, np.uint32)
+    oo = np.zeros(D + 1, np.uint64)
+    dbg = np.zeros(max(n, 1), np.uint8)
+    fl = np.zeros(max(D, 1), np.uint8)
+    nfl = ctypes.c_uint64(0)
+    nops = ctypes.c_uint64(0)
+    rc = lib().emu_flat_encode_batch(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special,
+                                     bos, eos, _p(data, ctypes.c_uint8), _p(offs, ctypes.c_uint64), D, int(add_bos),
+                                     int(add_eos), _p(out, ctypes.c_uint32), _p(oo, ctypes.c_uint64),
+                                     _p(dbg, ctypes.c_uint8), _p(fl, ctypes.c_uint8), ctypes.byref(nfl), ctypes.byref(nops))
+    if rc != 0:
+        raise RuntimeError("emu_flat_encode_batch rc=%d: %s" % (rc, lib().emu_last_error().decode()))
+    ids = [out[int(oo[d]):int(oo[d + 1])].tolist() for d in range(D)]
+    starts = []
+    for d in range(D):
+        a, b = int(offs[d]), int(offs[d + 1])
+        starts.append([i for i in range(b - a) if dbg[a + i]])
+    return ids, starts, [d for d in range(D) if fl[d]]

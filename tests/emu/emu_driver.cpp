@@ -10,6 +10,7 @@
 #include "tk_wave_emu.h"
 #include "../../include/tekken_hip.h"
 #include "../../tekken-rs_amd/csrc/tk_encode_impl.h"
+#include "../../tekken-rs_amd/csrc/tk_flat_impl.h"
 
 namespace tkemu {
 Wave* g_wave = nullptr;
@@ -79,6 +80,127 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
             memcpy(out_ids + t, staging.data() + doc_offs[d] + 2 * d, sizeof(uint32_t) * counts[d]);
             t += counts[d];
         }
+    }
+    out_offs[n_docs] = t;
+    return TK_OK;
+}
+
+// Flat path on the emulator: tk_flat_chunk for every chunk (one emulated wave), the flagged documents through
+// the per-document algorithm (mode 3, then pass 2), and host restatements of the small bookkeeping kernels of
+// tk_flat.hip (first_doc, todo list, chunk prefix sums, counts, assemble).
+extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
+                                     uint32_t bos, uint32_t eos, const uint8_t* bytes, const uint64_t* doc_offs,
+                                     uint64_t n_docs, int add_bos, int add_eos, uint32_t* out_ids, uint64_t* out_offs,
+                                     uint8_t* dbg_starts, uint8_t* out_flags, uint64_t* n_flagged, uint64_t* n_ops) {
+    TkHostTables T;
+    int rc = tk_build_tables(blob, offs, n_ranks, num_special, bos, eos, T, g_err);
+    if (rc != TK_OK) return rc;
+    const uint64_t n_bytes = doc_offs[n_docs];
+    const uint64_t n_chunks = (n_bytes + TKF_COMMIT - 1) / TKF_COMMIT;
+    std::vector<uint32_t> first_doc(n_chunks + 1, 0), tmp(n_chunks * TKF_STRIDE + 1, 0xDEADBEEFu), kcount(n_chunks + 1, 0);
+    std::vector<uint32_t> lstart(n_docs + 1, 0xDEADBEEFu), flags(n_docs + 1, 0);
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const int64_t lo = (int64_t)c * TKF_COMMIT - TKF_HL;
+        uint32_t k = 0;
+        while (k < n_docs && (int64_t)doc_offs[k] < (lo > 0 ? lo : 0)) ++k;
+        first_doc[c] = k;
+    }
+    TkFlatArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.bytes = bytes;
+    fa.doc_offs = doc_offs;
+    fa.n_docs = n_docs;
+    fa.n_bytes = n_bytes;
+    fa.n_chunks = n_chunks;
+    fa.first_doc = first_doc.data();
+    fa.tmp = tmp.data();
+    fa.kcount = kcount.data();
+    fa.lstart = lstart.data();
+    fa.flags = flags.data();
+    fa.dbg_starts = dbg_starts;
+    fa.t = T.host_view();
+    std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
+    uint64_t ops = 0;
+    if (n_chunks) {
+        tkemu::run_wave([&](int lane) {
+            TkPolyPow pw;
+            pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
+            for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
+        });
+        ops += tkemu::g_wave->n_ops;
+    }
+    // flagged documents -> per-document algorithm
+    std::vector<uint32_t> todo;
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (flags[d]) todo.push_back((uint32_t)d);
+    if (n_flagged) *n_flagged = todo.size();
+    if (out_flags) for (uint64_t d = 0; d < n_docs; ++d) out_flags[d] = (uint8_t)flags[d];
+    std::vector<uint32_t> staging(n_bytes + 2 * n_docs + 1, 0xDEADBEEFu), counts(n_docs + 1, 0), defer_list(n_docs + 1, 0);
+    if (!todo.empty()) {
+        uint32_t work_counter = 0, defer_count = 0;
+        TkEncodeArgs a;
+        memset(&a, 0, sizeof(a));
+        a.bytes = bytes;
+        a.doc_offs = doc_offs;
+        a.n_docs = n_docs;
+        a.staging = staging.data();
+        a.counts = counts.data();
+        a.work_counter = &work_counter;
+        a.defer_list = defer_list.data();
+        a.defer_count = &defer_count;
+        a.todo_list = todo.data();
+        a.n_todo = (uint32_t)todo.size();
+        a.add_bos = add_bos;
+        a.add_eos = add_eos;
+        a.t = T.host_view();
+        tkemu::run_wave([&](int lane) { tk_encode_wave<3>(a, lane, 0); });
+        ops += tkemu::g_wave->n_ops;
+        if (defer_count) {
+            uint64_t maxlen = 0;
+            for (uint32_t i = 0; i < defer_count; ++i)
+                maxlen = std::max<uint64_t>(maxlen, doc_offs[defer_list[i] + 1] - doc_offs[defer_list[i]]);
+            std::vector<uint32_t> scratch_raw(4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
+            uint32_t* scratch_al = scratch_raw.data();
+            while (reinterpret_cast<uintptr_t>(scratch_al) % 16) ++scratch_al;
+            std::vector<uint32_t> todo2(defer_list.begin(), defer_list.begin() + defer_count);
+            a.todo_list = todo2.data();
+            a.n_todo = defer_count;
+            a.scratch = scratch_al;
+            a.scratch_words_per_wave = scratch_raw.size() - 8;
+            work_counter = 0;
+            uint32_t dc2 = 0;
+            a.defer_count = &dc2;
+            tkemu::run_wave([&](int lane) { tk_encode_wave<1>(a, lane, 0); });
+            ops += tkemu::g_wave->n_ops;
+            if (dc2 != 0) { g_err = "pass 2 deferred a document"; return TK_ERR_RUNTIME; }
+        }
+    }
+    if (n_ops) *n_ops = ops;
+    // chunk prefix sums, counts, assemble (host restatement of tk_flat.hip's bookkeeping kernels)
+    std::vector<uint64_t> P(n_chunks + 1, 0);
+    for (uint64_t c = 0; c < n_chunks; ++c) P[c + 1] = P[c] + kcount[c];
+    auto G = [&](uint64_t i) -> uint64_t {
+        const uint64_t p = doc_offs[i];
+        if (p >= n_bytes) return P[n_chunks];
+        return P[p / TKF_COMMIT] + lstart[i];
+    };
+    uint64_t t = 0;
+    for (uint64_t d = 0; d < n_docs; ++d) {
+        out_offs[d] = t;
+        if (flags[d]) {
+            memcpy(out_ids + t, staging.data() + doc_offs[d] + 2 * d, sizeof(uint32_t) * counts[d]);
+            t += counts[d];
+            continue;
+        }
+        const uint64_t g0 = G(d), g1 = G(d + 1);
+        if (add_bos) out_ids[t++] = T.bos_id;
+        uint64_t g = g0, c = doc_offs[d] / TKF_COMMIT;
+        while (g < g1) {
+            const uint64_t hi = g1 < P[c + 1] ? g1 : P[c + 1];
+            for (; g < hi; ++g) out_ids[t++] = tmp[c * TKF_STRIDE + (g - P[c])];
+            ++c;
+        }
+        if (add_eos) out_ids[t++] = T.eos_id;
     }
     out_offs[n_docs] = t;
     return TK_OK;

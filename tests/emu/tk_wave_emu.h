@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <ucontext.h>
 
 #include <functional>
@@ -194,5 +195,24 @@ TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) {
     tkemu::yield_op(tkemu::OP_ATOMIC);
     return tkemu::g_wave->snap_u32[0] + (uint32_t)lane * v;
 }
+
+// ---- primitives of the flat (chunk-per-wave) path ----
+TK_DEV bool wv_inverse_ballot(uint64_t m) { return (m >> tkemu::g_wave->cur) & 1ull; }
+
+TK_DEV uint32_t wv_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 0xFFu;
+        if (s > 7) { fprintf(stderr, "tkemu: wv_perm selector %u not modelled\n", s); abort(); }
+        r |= (uint32_t)((v >> (8 * s)) & 0xFFull) << (8 * i);
+    }
+    return r;
+}
+
+TK_DEV void wv_lds_sync() { tkemu::yield_op(tkemu::OP_SYNC); }
+TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+
+TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) { memcpy(x, p, 16); }
 
 #endif

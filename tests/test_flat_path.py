@@ -1,0 +1,110 @@
+"""The FLAT path (tekken-rs_amd/csrc/tk_flat_impl.h: one wave per 1024-byte region of the packed stream, masks
+in lane layout, document boundaries as a mask) on the CPU:
+  * tools/flat_split_model.py -- the rules as mask algebra on Python ints -- against the oracle split;
+  * the device source on the wave emulator (tests/emu) against the oracle, id for id, including the
+    documents the fast path hands back to the per-document algorithm."""
+import itertools
+import random
+
+import corpus
+import emu
+import flat_split_model as fm
+import helpers
+import tk_oracle
+
+
+def _model_check(docs, **kw):
+    data = b"".join(docs)
+    offs = [0]
+    for d in docs:
+        offs.append(offs[-1] + len(d))
+    starts, deferred = fm.flat_split_chunked(data, offs, **kw)
+    exp = []
+    for i, d in enumerate(docs):
+        if i not in deferred:
+            exp += [offs[i] + s for s in tk_oracle.split(d)]
+    assert starts == exp
+    return deferred
+
+
+def test_model_baseline_shapes():
+    d, o = corpus.generate("ascii", 300, 512, seed=corpus.BASE_SEED + 1)
+    assert not _model_check(corpus.docs_of(d, o))          # nothing handed back on the headline workload
+    d, o = corpus.generate("zipf", 200, seed=corpus.BASE_SEED + 4)
+    _model_check([x for x in corpus.docs_of(d, o) if len(x) < 9000])
+    _model_check(helpers.EDGE_DOCS)
+
+
+def test_model_exhaustive_small_alphabet_packed():
+    """every string of length <= 5 over an 8-symbol alphabet, packed into ONE stream: document boundaries
+    fall at every offset of the lanes and of the chunk."""
+    alpha = ["a", "s", "1", "'", "!", " ", "\n", "\t"]
+    docs = ["".join(t).encode() for n in range(0, 6) for t in itertools.product(alpha, repeat=n)]
+    assert not _model_check(docs, region=256)
+
+
+def test_model_random_and_runs():
+    rng = random.Random(5)
+    alpha = list("aSstrelvmdx12'! \n\r\t-") + [" "] * 3
+    for _ in range(120):
+        docs = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, rng.choice([3, 40, 300])))).encode()
+                for _ in range(rng.randint(1, 40))]
+        _model_check(docs, region=rng.choice([256, 1024]))
+    alpha2 = list("a1 \n!'s")
+    for _ in range(120):
+        docs = ["".join(rng.choice(alpha2) * rng.choice([1, 1, 1, 2, 5, 40, 100]) for _ in range(rng.randint(0, 30))).encode()
+                for _ in range(rng.randint(1, 10))]
+        _model_check(docs, region=256)
+
+
+def _emu_check(v, docs, bos=True, eos=True, check_split=True):
+    o = helpers.oracle_for(v)
+    ids, starts, flagged = emu.flat_encode_batch(v["tokens"], v["num_special"], v["bos"], v["eos"], docs, bos, eos)
+    for i, d in enumerate(docs):
+        assert ids[i] == o.encode(d, bos, eos), (i, d[:80], i in flagged)
+        if check_split and i not in flagged:
+            assert starts[i] == tk_oracle.split(d), (i, d[:80])
+    return flagged
+
+
+def test_emu_flat_baseline_shapes(test_vocab):
+    d, o = corpus.generate("ascii", 40, 512, seed=corpus.BASE_SEED + 1)
+    assert _emu_check(test_vocab, corpus.docs_of(d, o)) == []
+    d, o = corpus.generate("zipf", 60, seed=corpus.BASE_SEED + 4)
+    _emu_check(test_vocab, [x for x in corpus.docs_of(d, o) if len(x) < 6000])
+    for bos, eos in ((False, False), (True, False)):
+        _emu_check(test_vocab, helpers.EDGE_DOCS, bos, eos)
+
+
+def test_emu_flat_handback_and_mixed(test_vocab):
+    docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120)
+    flagged = _emu_check(test_vocab, docs)
+    assert flagged and len(flagged) < len(docs)           # both routes were taken inside one stream
+    # empty documents in every position, a single document, only empty documents
+    _emu_check(test_vocab, [b"", b"ab cd", b"", b"", b"x" * 100, b""])
+    _emu_check(test_vocab, [b"hello world"])
+    _emu_check(test_vocab, [b"", b""])
+
+
+def test_emu_flat_small_alphabet_packed(small_vocab):
+    alpha = ["a", "s", "1", "'", "!", " ", "\n", "\t"]
+    docs = ["".join(t).encode() for n in range(0, 5) for t in itertools.product(alpha, repeat=n)]
+    _emu_check(small_vocab, docs, False, False)
+
+
+def test_emu_flat_runs_and_misses(test_vocab):
+    """digit / white-space / CR-LF runs across lanes and chunk boundaries; random letter strings (pieces that
+    miss the vocabulary: the packed-window merge, several pieces per window, extra ids shifting later slots)."""
+    rng = random.Random(21)
+    alpha = ["a", "b", "1", "2", "'", "s", "t", "!", "-", " ", " ", " ", "\n", "\r", "\t"]
+    docs = []
+    for _ in range(120):
+        n = rng.randint(60, 700)
+        parts = []
+        while sum(map(len, parts)) < n:
+            parts.append(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 5, 9, 17, 40]))
+        docs.append("".join(parts).encode())
+    _emu_check(test_vocab, docs)
+    words = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(1, 30))) for _ in range(3000)]
+    docs = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 120))).encode() for _ in range(25)]
+    assert _emu_check(test_vocab, docs) == []

@@ -101,6 +101,49 @@ def test_baseline_shapes_bench_vocab(eng_bench, bench_vocab, kind, n, dl, seed):
         assert eng_bench.last_stats()["long_docs"] > 0  # the long-piece second pass ran
 
 
+def test_both_pipelines(tk, test_vocab, monkeypatch):
+    """The flat chunk-per-wave pipeline (default) and the per-document pipeline (TK_PIPELINE=doc) give the same ids;
+    the flat one hands non-ASCII / long-run documents back and says how many."""
+    orc = helpers.oracle_for(test_vocab)
+    docs = helpers.mixed_docs(120, 40, 200, max_len=40000) + helpers.random_unicode_docs(300)
+    exp = [orc.encode(d, True, True) for d in docs]
+    flat = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    assert flat.encode_docs(docs, True, True) == exp
+    st = flat.last_stats()
+    assert 0 < st["handed_back"] < len(docs)
+    flat.close()
+    monkeypatch.setenv("TK_PIPELINE", "doc")
+    per_doc = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    assert per_doc.encode_docs(docs, True, True) == exp
+    assert per_doc.last_stats()["handed_back"] == 0
+    per_doc.close()
+
+
+def test_flat_path_stress(eng_small, test_vocab):
+    """What the flat path is sensitive to: documents of every length packed back to back (boundaries at every lane /
+    chunk offset), many empty documents, pieces that miss the vocabulary in bulk, long runs across chunk boundaries."""
+    import random
+    orc = helpers.oracle_for(test_vocab)
+    rng = random.Random(11)
+    docs = [b"x" * n for n in range(0, 130)] + [b"ab " * n for n in range(0, 400, 7)] + [b""] * 50
+    words = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(1, 30))) for _ in range(5000)]
+    docs += [" ".join(rng.choice(words) for _ in range(rng.randint(1, 400))).encode() for _ in range(300)]
+    alpha = ["a", "b", "1", "2", "'", "s", "t", "!", "-", " ", " ", " ", "\n", "\r", "\t"]
+    for _ in range(400):
+        n = rng.randint(10, 3000)
+        parts = []
+        while sum(map(len, parts)) < n:
+            parts.append(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 5, 9, 17, 40, 70]))
+        docs.append("".join(parts).encode())
+    docs += ["".join(rng.choice("abc123 ,.\n") for _ in range(rng.randint(0, 50))).encode() for _ in range(3000)]
+    rng.shuffle(docs)
+    data = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs])
+    for bos, eos in ((True, True), (False, False)):
+        check_batch(eng_small, orc, data, offs, bos, eos)
+
+
 def test_edge_batches(eng_small, test_vocab):
     orc = helpers.oracle_for(test_vocab)
     # empty batch, only-empty docs, one empty doc between others

@@ -2,6 +2,7 @@
 //
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
 //   tk_flat_kernel            split + lookup + merge of one 1024-byte region per wave, ids chunk-dense
+//   tk_merge_kernel           byte-pair merge of the queued pieces that missed the vocabulary, one lane per piece
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel
 //   tk_flat_counts_kernel     ids per document from the chunk prefix sums and the document-start ranks
 //   tk_flat_assemble_kernel   chunk-dense ids -> packed ids in document order with BOS / EOS
@@ -43,6 +44,14 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
     for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
+__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKM_LDS_WORDS];
+    const int lane = wv_lane();
+    uint32_t* lds = lds_all + (threadIdx.x >> 6) * TKM_LDS_WORDS;
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
+    tk_merge_wave(a, wave, lane, lds);
+}
+
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
                                                                   uint32_t* __restrict__ todo, uint32_t* __restrict__ n_todo) {
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
@@ -68,13 +77,14 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_
                                                                     uint64_t n_bytes, uint64_t n_chunks,
                                                                     const uint64_t* __restrict__ P,
                                                                     const uint32_t* __restrict__ lstart,
-                                                                    const uint32_t* __restrict__ flags, uint32_t extra,
+                                                                    const uint32_t* __restrict__ flags,
+                                                                    const uint32_t* __restrict__ holes, uint32_t extra,
                                                                     uint32_t* __restrict__ counts) {
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
     if (d >= n_docs || flags[d]) return;  // a flagged document keeps the count of the per-document kernel
     const uint64_t g0 = tkf_G(doc_offs, d, n_bytes, n_chunks, P, lstart);
     const uint64_t g1 = tkf_G(doc_offs, d + 1, n_bytes, n_chunks, P, lstart);
-    counts[d] = (uint32_t)(g1 - g0) + extra;
+    counts[d] = (uint32_t)(g1 - g0) - holes[d] + extra;
 }
 
 struct TkFlatAssembleArgs {
@@ -112,14 +122,19 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
         }
         uint64_t g = g0;
         uint64_t c = a.doc_offs[d] / TKF_COMMIT;
-        while (g < g1) {  // ids [g, g1) live chunk-dense: id g of chunk c at tmp[c * STRIDE + g - P[c]]
+        while (g < g1) {  // slots [g, g1) live chunk-dense: slot g of chunk c at tmp[c * STRIDE + g - P[c]]; holes are skipped
             const uint64_t pc = a.P[c], pn = a.P[c + 1];
             const uint64_t hi = g1 < pn ? g1 : pn;
             if (hi > g) {
                 const uint32_t* src = a.tmp + c * TKF_STRIDE + (g - pc);
                 const uint32_t nn = (uint32_t)(hi - g);
-                for (uint32_t k = (uint32_t)lane; k < nn; k += 64u) dst[k] = src[k];
-                dst += nn;
+                for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const uint32_t v = k < nn ? src[k] : TKF_HOLE;
+                    const uint64_t keep = __ballot(v != TKF_HOLE);
+                    if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
+                    dst += __builtin_popcountll(keep);
+                }
                 g = hi;
             }
             ++c;
@@ -150,6 +165,13 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
+    if (a.n_chunks == 0) return hipSuccess;
+    const uint64_t waves = (a.n_chunks + TKM_GROUP - 1) / TKM_GROUP;
+    hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((waves + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_flat_todo_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, flags, n_docs, todo, n_todo);
@@ -157,11 +179,11 @@ hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t*
 }
 
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
-                                 const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, uint32_t extra,
-                                 uint32_t* counts, hipStream_t s) {
+                                 const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,
+                                 uint32_t extra, uint32_t* counts, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_flat_counts_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs, n_bytes,
-                       n_chunks, P, lstart, flags, extra, counts);
+                       n_chunks, P, lstart, flags, holes, extra, counts);
     return hipGetLastError();
 }
 

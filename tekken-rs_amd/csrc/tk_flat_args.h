@@ -10,6 +10,8 @@
 #define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
 #define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* 928 bytes committed per chunk */
 #define TKF_STRIDE (TKF_COMMIT + 64)                 /* id slots per chunk: a piece may reach 63 bytes past the commit range */
+#define TKF_MISSCAP (TKF_COMMIT / 2)                  /* queue records per chunk: a queued piece has >= 2 bytes */
+#define TKF_HOLE 0xFFFFFFFFu                         /* id slot reserved by a missed piece and not used */
 
 struct TkFlatArgs {
     const uint8_t* bytes;        // packed text of all documents
@@ -17,10 +19,15 @@ struct TkFlatArgs {
     uint64_t n_docs, n_bytes, n_chunks;
     const uint32_t* first_doc;   // [n_chunks] documents that start below the chunk's loaded region
     uint32_t* tmp;               // [n_chunks * TKF_STRIDE] chunk-dense ids
-    uint32_t* kcount;            // [n_chunks] ids of the chunk
-    uint32_t* lstart;            // [n_docs] ids of the chunk before the document's first byte
+    uint32_t* kcount;            // [n_chunks] id slots of the chunk (holes included)
+    uint32_t* lstart;            // [n_docs] id slots of the chunk before the document's first byte
+    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17
+    uint32_t* miss_count;        // [n_chunks] queued pieces of the chunk
+    uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
+    int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,
+                                 // 8 stop after the split rules, 16 stop after the classification
     TkTablesView t;
 };
 

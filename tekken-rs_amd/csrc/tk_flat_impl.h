@@ -11,16 +11,18 @@
 //     shifts at a document end, runs are broken there -- documents never cost a branch;
 //   * piece starts are enumerated into LDS and probed ONE LANE PER PIECE (64 probes per instruction
 //     instead of ~13 with one lane per byte);
-//   * pieces that miss the vocabulary are packed, many per 64-lane window, and merged with the
-//     lane-parallel segmented-min rounds of tk_encode_impl.h (tiktoken's order);
-//   * ids are written chunk-dense (chunk c at tmp[c*TKF_STRIDE ..]), K[c] ids per chunk; the rank of
-//     every document start inside its chunk (lstart) lets tk_flat_assemble cut them into documents.
+//   * a piece that misses the vocabulary reserves `len` id slots and is queued; tk_merge_wave merges the
+//     queue ONE LANE PER PIECE (tiktoken's order) -- 64 independent chains of dependent
+//     PAIR probes per wave at high occupancy -- and marks the slots it does not need as holes;
+//   * ids are written chunk-dense (chunk c at tmp[c*TKF_STRIDE ..]), K[c] slots per chunk; the slot of
+//     every document start inside its chunk (lstart) and the holes per document let tk_flat_assemble
+//     cut the stream into documents and squeeze the holes out.
 //
 // Regions overlap: 32 bytes of left halo (look-behind context), 64 of right halo (look-ahead, piece
 // ends), 928 committed.  The fast path is ASCII; a document with a byte >= 0x80, with a digit / CR-LF
-// run that covers the whole left halo, a white-space run that reaches the end of the region, a piece
-// of more than 64 bytes, or in a chunk with more than TKF_MAXMISS missed pieces is flagged and redone
-// by the per-document kernel (tk_encode_impl.h), which handles everything.
+// run that covers the whole left halo, a white-space run that reaches the end of the region or a piece
+// of more than 64 bytes is flagged and redone by the per-document kernel (tk_encode_impl.h), which
+// handles everything.
 //
 // The rules are modelled in tools/flat_split_model.py (Python ints as masks, checked against the
 // oracle); this file is that model in lane layout.  Runs on the CPU wave emulator (tests/emu).
@@ -33,23 +35,15 @@
 
 #define TKF_W 16
 #define TKF_WM 0xFFFFu
-#define TKF_MAXMISS 256
-#define TKF_MISS 0xFFFFFFFEu
-#define TKF_MAXBATCH ((TKF_REGION + 63) / 64 + 1)
 
 // LDS words of one wave
-#define TKF_L_LIST 0                                /* [REGION + 2] piece positions, then parked ranks */
+#define TKF_L_LIST 0                                /* [REGION + 2] piece positions, then the id slot of every piece */
 #define TKF_L_DS (TKF_L_LIST + TKF_REGION + 2)      /* [64] document-start mask words */
 #define TKF_L_PS (TKF_L_DS + 64)                    /* [64] owned piece-start mask words */
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
 #define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
-#define TKF_L_MREC (TKF_L_BPFX + 64)                /* [MAXMISS] pos | len << 16 */
-#define TKF_L_MIDX (TKF_L_MREC + TKF_MAXMISS)       /* [MAXMISS] piece index */
-#define TKF_L_CUMX (TKF_L_MIDX + TKF_MAXMISS)       /* [MAXMISS] extra ids up to and including this miss */
-#define TKF_L_MARK (TKF_L_CUMX + TKF_MAXMISS)       /* [64] packed-window piece starts */
-#define TKF_L_MB (TKF_L_MARK + 64)                  /* [3 * MAXBATCH] miss ballot lo, hi, misses before the batch */
-#define TKF_LDS_WORDS (TKF_L_MB + 3 * TKF_MAXBATCH)
+#define TKF_LDS_WORDS (TKF_L_BPFX + 64)
 
 
 // ------------------------------------------------------------------------------------------
@@ -249,6 +243,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
     }
     const TkfClass m = tkf_classify(x);
+    if (a.dbg_ablate & 16) {
+        if (lane == 0) a.kcount[c] = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
+        return;
+    }
 
     // ---- 2. document starts inside the region -> DS (lane layout, through LDS) ------------------
     lds[TKF_L_DS + lane] = 0u;
@@ -275,6 +273,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // ---- 3. piece starts ---------------------------------------------------------------------------
     uint32_t SPR, cont;
     const uint32_t PS = tkf_rules(m, DS, lane, &SPR, &cont);
+    if (a.dbg_ablate & 8) {
+        if (lane == 0) a.kcount[c] = PS + SPR + cont;
+        return;
+    }
     const uint32_t commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
     if (a.dbg_starts) {
         for (int k = 0; k < 16; ++k)
@@ -329,10 +331,13 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     lds[TKF_L_PFX + lane] = pfx_own;
     wv_lds_sync();
 
-    // ---- 6. whole-piece lookup, one lane per piece ---------------------------------------------------
+    // ---- 6. whole-piece lookup, one lane per piece; ids stored at once ---------------------------------
+    // A piece that misses the vocabulary reserves `len` id slots (it cannot produce more ids than bytes) and is
+    // queued for tk_merge_wave; the slots it does not fill stay TKF_HOLE and are squeezed out by the assembly.
     const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
+    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
+    uint32_t E = 0;                                         // slots beyond one per piece so far
     uint32_t nmiss = 0;
-    bool overflow = false;
     const uint32_t nbatch = (np_own + 63u) / 64u;
     for (uint32_t j = 0; j < nbatch; ++j) {
         const uint32_t idx = j * 64u + (uint32_t)lane;
@@ -344,7 +349,9 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
         uint32_t r = 0;
         bool toolong = false;
-        if (act) {
+        if (a.dbg_ablate & 1) {
+            r = 7u;
+        } else if (act) {
             if (len > 64u) {
                 toolong = true;
             } else if (len == 1u) {
@@ -374,121 +381,33 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
         if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> 4), 1u << (pos & 15));
-        const bool miss = act && !toolong && r == TK_RANK_MAX;
+        const bool miss = act && !toolong && r == TK_RANK_MAX && !(a.dbg_ablate & 2);
         const uint64_t MB = wv_ballot(miss);
-        if (lane == 0) {
-            lds[TKF_L_MB + 3 * j] = (uint32_t)MB;
-            lds[TKF_L_MB + 3 * j + 1] = (uint32_t)(MB >> 32);
-            lds[TKF_L_MB + 3 * j + 2] = nmiss;
-        }
-        if (miss) {
-            const uint32_t slot = nmiss + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
-            if (slot < TKF_MAXMISS) {
-                lds[TKF_L_MREC + slot] = pos | (len << 16);
-                lds[TKF_L_MIDX + slot] = idx;
+        uint32_t slot = idx + E;
+        if (MB) {
+            // slots of the batch: one per piece + (len - 1) more for every miss before it
+            uint32_t tot;
+            slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
+            E += tot;
+            // queue the misses in the chunk's own region (no global atomics), records in piece order
+            if (miss) {
+                const uint32_t mi = nmiss + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
+                a.miss_list[c * TKF_MISSCAP + mi] = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
             }
+            nmiss += (uint32_t)tk_popc64(MB);
         }
-        nmiss += (uint32_t)tk_popc64(MB);
         wv_lds_sync();                                      // positions read before they are overwritten
-        if (act) list[idx] = miss ? TKF_MISS : (toolong ? 0u : r);
-    }
-    if (nmiss > TKF_MAXMISS) {
-        overflow = true;
-        nmiss = 0;
-        BAD |= commit_mask;
-    }
-    wv_lds_sync();
-
-    // ---- 7. merge the pieces that missed: many pieces per 64-lane window ----------------------------
-    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
-    uint32_t E = 0;                                         // extra ids (beyond one per piece) so far
-    for (uint32_t cur = 0; cur < nmiss;) {
-        const uint32_t mi_me = cur + (uint32_t)lane;
-        const uint32_t rec = mi_me < nmiss ? lds[TKF_L_MREC + mi_me] : 0u;
-        const uint32_t pidx_me = mi_me < nmiss ? lds[TKF_L_MIDX + mi_me] : 0u;
-        const uint32_t mylen = mi_me < nmiss ? (rec >> 16) : 1000u;
-        uint32_t incl = mylen;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = wv_shfl(incl, lane >= d ? lane - d : lane);
-            if (lane >= d) incl += o;
-        }
-        const uint64_t TAKE = wv_ballot(incl <= 64u);       // a prefix of the lanes; never empty (len <= 64)
-        const int ntake = tk_popc64(TAKE);
-        const uint32_t total = wv_shfl(incl, ntake - 1);
-        lds[TKF_L_MARK + lane] = 0u;
-        wv_lds_sync();
-        if (lane < ntake) lds[TKF_L_MARK + (incl - mylen)] = (uint32_t)lane + 1u;
-        wv_lds_sync();
-        const uint32_t mark = lds[TKF_L_MARK + lane];
-        const uint64_t Sm = wv_ballot(mark != 0u);          // piece starts of the packed window
-        const int ps = tk_msb64(Sm & tk_lowmask(lane + 1));
-        const int mi = (int)wv_shfl(mark, ps) - 1;          // which taken piece this lane belongs to
-        const uint32_t prec = wv_shfl(rec, mi & 63);
-        const uint32_t pidx = wv_shfl(pidx_me, mi & 63);
-        const bool inmiss = (uint32_t)lane < total;
-        const uint32_t ppos = prec & 0xFFFFu, plen = prec >> 16;
-        const int pe = ps + (int)plen;
-        const uint32_t b0 = inmiss ? (uint32_t)rbytes[ppos + (uint32_t)(lane - ps)] : 0u;
-        const uint32_t b1 = wv_up1(b0);
-        // (the rounds of tk_encode_impl.h step 5: one merge per piece per round, leftmost minimum rank)
-        uint64_t A = wv_ballot(inmiss);
-        uint32_t tok = b0;
-        uint32_t prank = TK_RANK_MAX;
-        if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
-        const int sl = pe - 1 < 63 ? pe - 1 : 63;
-        for (int round = 0; round < 64; ++round) {
-            const uint32_t key = prank == TK_RANK_MAX ? 0xFFFFFFFFu : ((prank << 6) | (uint32_t)lane);
-            uint32_t mn = key;
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t o = wv_shfl(mn, lane >= dd ? lane - dd : lane);
-                if (lane >= dd && lane - dd >= ps) mn = o < mn ? o : mn;
-            }
-            const uint32_t segmin = wv_shfl(mn, sl);
-            const bool winner = inmiss && key != 0xFFFFFFFFu && key == segmin;
-            const uint64_t Wm = wv_ballot(winner);
-            if (!Wm) break;
-            const bool alive = tk_bit(A, lane);
-            const uint64_t below = A & tk_lowmask(lane);
-            const bool dead = alive && below && tk_bit(Wm, tk_msb64(below));
-            const uint64_t Dm = wv_ballot(dead);
-            A &= ~Dm;
-            if (winner) tok = prank;
-            if (dead) prank = TK_RANK_MAX;
-            const uint64_t z = lane < 63 ? (A >> (lane + 1)) : 0ull;
-            const int na = z ? lane + 1 + tk_ctz64(z) : 64;
-            const bool has_next = na < pe;
-            const uint32_t tn = wv_shfl(tok, na < 64 ? na : lane);
-            const bool need = tk_bit(A, lane) && (winner || (has_next && tk_bit(Wm, na)));
-            if (need) prank = has_next ? tk_probe_pair(t, tok, tn) : TK_RANK_MAX;
-        }
-        const uint64_t SUB = A & ~Sm;                       // surviving parts that are not piece heads
-        if (inmiss && tk_bit(A, lane))
-            tmp[pidx + E + (uint32_t)tk_popc64(SUB & tk_lowmask(lane + 1))] = tok + t.num_special;
-        if (inmiss && lane == ps) lds[TKF_L_CUMX + cur + (uint32_t)mi] = E + (uint32_t)tk_popc64(SUB & tk_lowmask(pe));
-        E += (uint32_t)tk_popc64(SUB);
-        cur += (uint32_t)ntake;
-    }
-    wv_lds_sync();
-
-    // ---- 8. emit the hits: id slot = piece index + extra ids of the misses before it ----------------
-    for (uint32_t j = 0; j < nbatch; ++j) {
-        const uint32_t idx = j * 64u + (uint32_t)lane;
-        if (idx < np_own) {
-            const uint32_t tv = list[idx];
-            if (tv != TKF_MISS) {
-                uint32_t extra = 0;
-                if (nmiss) {
-                    const uint64_t MB = ((uint64_t)lds[TKF_L_MB + 3 * j + 1] << 32) | lds[TKF_L_MB + 3 * j];
-                    const uint32_t nm = lds[TKF_L_MB + 3 * j + 2] + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
-                    if (nm) extra = lds[TKF_L_CUMX + nm - 1];
-                }
-                tmp[idx + extra] = tv + t.num_special;
-            }
+        if (act) {
+            list[idx] = slot;                               // step 7 looks the slot of a document start up here
+            if (!miss && !(a.dbg_ablate & 4)) tmp[slot] = r + t.num_special;
         }
     }
-    if (lane == 0) a.kcount[c] = np_own + E;
+    if (lane == 0) {
+        a.kcount[c] = np_own + E;
+        a.miss_count[c] = nmiss;
+    }
 
-    // ---- 9. per-document outputs: rank of every document start, fall-back flags ---------------------
+    // ---- 7. per-document outputs: slot of every document start, fall-back flags ---------------------
     BAD |= lds[TKF_L_BAD + lane];                           // piece-level marks of step 6
     const bool anybad = tkf_any(BAD);
     if (anybad) {
@@ -496,9 +415,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         const uint32_t bp = tkf_scan_excl((uint32_t)__builtin_popcount(BAD), lane, &nb);
         lds[TKF_L_BAD + lane] = BAD;
         lds[TKF_L_BPFX + lane] = bp;
-        wv_lds_sync();
     }
-    (void)overflow;
+    wv_lds_sync();
     {
         // documents that touch the commit range: fd - 1 (the one that contains the region start) onwards
         const uint64_t dfirst = fd > 0 ? fd - 1 : 0;
@@ -511,22 +429,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
             const bool in = s < c1;
             if (in && s >= c0) {
-                // ids of this chunk before the document's first byte
+                // id slots of this chunk before the document's first byte (a document start is a piece start)
                 const uint32_t p = (uint32_t)(s - r0);
                 const uint32_t pi = lds[TKF_L_PFX + (p >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_PS + (p >> 4)] & ((1u << (p & 15)) - 1u));
-                uint32_t extra = 0;
-                if (nmiss) {
-                    const uint32_t jb = pi >> 6, q = pi & 63u;
-                    uint32_t nm;
-                    if (jb < nbatch) {
-                        const uint64_t MB = ((uint64_t)lds[TKF_L_MB + 3 * jb + 1] << 32) | lds[TKF_L_MB + 3 * jb];
-                        nm = lds[TKF_L_MB + 3 * jb + 2] + (uint32_t)tk_popc64(MB & tk_lowmask((int)q));
-                    } else {
-                        nm = nmiss;
-                    }
-                    if (nm) extra = lds[TKF_L_CUMX + nm - 1];
-                }
-                a.lstart[d] = pi + extra;
+                a.lstart[d] = pi < np_own ? list[pi] : np_own + E;
             }
             if (anybad && in && e > c0) {
                 // any bad position inside [s, e) clipped to the region?
@@ -544,6 +450,154 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
     }
     wv_lds_sync();  // the next chunk reuses the LDS slice
+}
+
+// ------------------------------------------------------------------------------------------
+// tk_merge_wave: byte-pair merge of 64 queued pieces, ONE LANE PER PIECE (tiktoken's _byte_pair_merge,
+// repeatedly merge the leftmost minimum-rank adjacent pair).  Every lane runs its own
+// chain of dependent PAIR probes, 64 chains per wave and many waves per SIMD hide their latency.
+// Pieces of up to TKM_SHORT bytes keep their parts in LDS ([part][lane], conflict-free); the rare longer
+// ones (<= 64 bytes) are merged one at a time, one lane per byte, with the segmented-min rounds.
+// The ids go to the `len` slots the flat kernel reserved; unused slots become TKF_HOLE and the
+// document's hole count is raised so that tk_flat_counts / assemble can squeeze them out.
+// ------------------------------------------------------------------------------------------
+#define TKM_SHORT 16
+#define TKM_LDS_WORDS (2 * TKM_SHORT * 64)
+
+#define TKM_GROUP 16 /* chunks whose queues one wave takes */
+
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* lds);
+
+TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* lds) {
+    // the queues of TKM_GROUP consecutive chunks, 64 pieces at a time
+    const uint64_t cbase = wave_id * TKM_GROUP;
+    uint32_t cnt = 0;
+    if (lane < TKM_GROUP && cbase + (uint64_t)lane < a.n_chunks) cnt = a.miss_count[cbase + lane];
+    uint32_t total;
+    const uint32_t excl = tkf_scan_excl(cnt, lane, &total);
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t item = base + (uint32_t)lane;
+        // chunk of the item: the last queue whose first item is <= item
+        uint32_t k = 0, first = 0;
+        for (int q = 1; q < TKM_GROUP; ++q) {
+            const uint32_t eq = wv_readlane(excl, q), nq = wv_readlane(cnt, q);
+            if (nq != 0u && eq <= item) { k = (uint32_t)q; first = eq; }
+        }
+        const bool have = item < total;
+        uint32_t rec = 0;
+        if (have) rec = a.miss_list[(cbase + k) * TKF_MISSCAP + (item - first)];
+        tk_merge_items(a, have, rec, (uint32_t)(cbase + k), lane, lds);
+    }
+}
+
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* lds) {
+    const TkTablesView& t = a.t;
+    const uint32_t pos = rec & 1023u, len = (rec >> 10) & 127u, slot = rec >> 17;
+    const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
+    uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
+    uint32_t* tokL = lds;                       // [TKM_SHORT][64]
+    uint32_t* prkL = lds + TKM_SHORT * 64;      // [TKM_SHORT][64]
+    uint32_t holes = 0;
+
+    // ---- short pieces: sequential merge per lane ----------------------------------------------------
+    const bool isshort = have && len <= TKM_SHORT;
+    uint32_t np = isshort ? len : 0u;
+    if (isshort) {
+        uint32_t prev = a.bytes[g];
+        for (uint32_t i = 0; i < np; ++i) {
+            const uint32_t nxt = i + 1 < np ? (uint32_t)a.bytes[g + i + 1] : 0u;
+            tokL[i * 64 + lane] = prev;
+            prkL[i * 64 + lane] = i + 1 < np ? t.pair2[prev | (nxt << 8)] : TK_RANK_MAX;
+            prev = nxt;
+        }
+    }
+    bool active = isshort;
+    while (wv_ballot(active)) {
+        if (active) {
+            uint32_t best = TK_RANK_MAX, bi = 0;
+            for (uint32_t i = 0; i + 1 < np; ++i) {
+                const uint32_t rk = prkL[i * 64 + lane];
+                if (rk < best) { best = rk; bi = i; }
+            }
+            if (best == TK_RANK_MAX) {
+                active = false;
+            } else {
+                // parts bi and bi + 1 become one part whose id is the rank of the pair
+                for (uint32_t i = bi + 1; i + 1 < np; ++i) {
+                    tokL[i * 64 + lane] = tokL[(i + 1) * 64 + lane];
+                    prkL[i * 64 + lane] = prkL[(i + 1) * 64 + lane];
+                }
+                np -= 1;
+                tokL[bi * 64 + lane] = best;
+                const bool has_next = bi + 1 < np, has_prev = bi > 0;
+                const uint32_t tn = has_next ? tokL[(bi + 1) * 64 + lane] : 0u;
+                const uint32_t tp = has_prev ? tokL[(bi - 1) * 64 + lane] : 0u;
+                uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
+                if (has_next && has_prev) tk_probe_pair_x2(t, best, tn, tp, best, r_next, r_prev);
+                else if (has_next) r_next = tk_probe_pair(t, best, tn);
+                else if (has_prev) r_prev = tk_probe_pair(t, tp, best);
+                prkL[bi * 64 + lane] = r_next;
+                if (has_prev) prkL[(bi - 1) * 64 + lane] = r_prev;
+            }
+        }
+    }
+    if (isshort) {
+        for (uint32_t i = 0; i < len; ++i) out[i] = i < np ? tokL[i * 64 + lane] + t.num_special : TKF_HOLE;
+        holes = len - np;
+    }
+
+    // ---- long pieces (17..64 bytes): one at a time, one lane per byte ----------------------------------
+    uint64_t LONGM = wv_ballot(have && len > TKM_SHORT);
+    while (LONGM) {
+        const int src = tk_ctz64(LONGM);
+        LONGM &= LONGM - 1ull;
+        const uint32_t plen = wv_shfl(len, src);
+        const uint32_t glo = wv_shfl((uint32_t)g, src), ghi = wv_shfl((uint32_t)((uint64_t)g >> 32), src);
+        const int64_t pg = (int64_t)(((uint64_t)ghi << 32) | glo);
+        const uint32_t pchunk = wv_shfl(chunk, src), pslot = wv_shfl(slot, src);
+        uint32_t* pout = a.tmp + (uint64_t)pchunk * TKF_STRIDE + pslot;
+        const int pe = (int)plen;
+        const bool inmiss = lane < pe;
+        const uint32_t b0 = inmiss ? (uint32_t)a.bytes[pg + lane] : 0u;
+        const uint32_t b1 = wv_up1(b0);
+        uint64_t A = wv_ballot(inmiss);
+        uint32_t tok = b0;
+        uint32_t prank = TK_RANK_MAX;
+        if (inmiss && lane + 1 < pe) prank = t.pair2[b0 | (b1 << 8)];
+        for (int round = 0; round < 64; ++round) {
+            const uint32_t key = prank == TK_RANK_MAX ? 0xFFFFFFFFu : ((prank << 6) | (uint32_t)lane);
+            const uint32_t segmin = wv_min_u32(key);
+            if (segmin == 0xFFFFFFFFu) break;
+            const bool winner = key == segmin;
+            const uint64_t Wm = wv_ballot(winner);
+            const bool alive = tk_bit(A, lane);
+            const uint64_t below = A & tk_lowmask(lane);
+            const bool dead = alive && below && tk_bit(Wm, tk_msb64(below));
+            const uint64_t Dm = wv_ballot(dead);
+            A &= ~Dm;
+            if (winner) tok = prank;
+            if (dead) prank = TK_RANK_MAX;
+            const uint64_t z = lane < 63 ? (A >> (lane + 1)) : 0ull;
+            const int na = z ? lane + 1 + tk_ctz64(z) : 64;
+            const bool has_next = na < pe;
+            const uint32_t tn = wv_shfl(tok, na < 64 ? na : lane);
+            const bool need = tk_bit(A, lane) && (winner || (has_next && tk_bit(Wm, na)));
+            if (need) prank = has_next ? tk_probe_pair(t, tok, tn) : TK_RANK_MAX;
+        }
+        const uint32_t k = (uint32_t)tk_popc64(A);
+        if (inmiss && tk_bit(A, lane)) pout[tk_popc64(A & tk_lowmask(lane))] = tok + t.num_special;
+        if (inmiss && (uint32_t)lane >= k) pout[lane] = TKF_HOLE;
+        if (lane == src) holes = plen - k;
+    }
+
+    // ---- the document of the piece loses `holes` ids ---------------------------------------------------
+    if (have && holes) {
+        // largest d with doc_offs[d] <= g: the documents from first_doc[chunk] - 1 on start at or above the region
+        uint64_t d = a.first_doc[chunk];
+        d = d > 0 ? d - 1 : 0;
+        while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
+        wv_atomic_add(a.holes + d, holes);
+    }
 }
 
 #endif

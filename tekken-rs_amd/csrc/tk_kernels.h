@@ -30,8 +30,9 @@ hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, ui
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
 hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
-                                 const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, uint32_t extra,
-                                 uint32_t* counts, hipStream_t s);
+                                 const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,
+                                 uint32_t extra, uint32_t* counts, hipStream_t s);
+hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);
 hipError_t tk_launch_flat_assemble(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
                                    const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* counts,
                                    const uint64_t* out_offs, const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids,

@@ -98,7 +98,8 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     const uint64_t n_bytes = doc_offs[n_docs];
     const uint64_t n_chunks = (n_bytes + TKF_COMMIT - 1) / TKF_COMMIT;
     std::vector<uint32_t> first_doc(n_chunks + 1, 0), tmp(n_chunks * TKF_STRIDE + 1, 0xDEADBEEFu), kcount(n_chunks + 1, 0);
-    std::vector<uint32_t> lstart(n_docs + 1, 0xDEADBEEFu), flags(n_docs + 1, 0);
+    std::vector<uint32_t> lstart(n_docs + 1, 0xDEADBEEFu), flags(n_docs + 1, 0), holes(n_docs + 1, 0);
+    std::vector<uint32_t> miss_list(n_chunks * TKF_MISSCAP + 16, 0), miss_count(n_chunks + 1, 0);
     for (uint64_t c = 0; c < n_chunks; ++c) {
         const int64_t lo = (int64_t)c * TKF_COMMIT - TKF_HL;
         uint32_t k = 0;
@@ -117,6 +118,9 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.kcount = kcount.data();
     fa.lstart = lstart.data();
     fa.flags = flags.data();
+    fa.miss_list = miss_list.data();
+    fa.miss_count = miss_count.data();
+    fa.holes = holes.data();
     fa.dbg_starts = dbg_starts;
     fa.t = T.host_view();
     std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
@@ -128,6 +132,11 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
         });
         ops += tkemu::g_wave->n_ops;
+        std::vector<uint32_t> mlds(TKM_LDS_WORDS, 0);
+        for (uint64_t w = 0; w * TKM_GROUP < n_chunks; ++w) {
+            tkemu::run_wave([&](int lane) { tk_merge_wave(fa, w, lane, mlds.data()); });
+            ops += tkemu::g_wave->n_ops;
+        }
     }
     // flagged documents -> per-document algorithm
     std::vector<uint32_t> todo;
@@ -197,7 +206,10 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         uint64_t g = g0, c = doc_offs[d] / TKF_COMMIT;
         while (g < g1) {
             const uint64_t hi = g1 < P[c + 1] ? g1 : P[c + 1];
-            for (; g < hi; ++g) out_ids[t++] = tmp[c * TKF_STRIDE + (g - P[c])];
+            for (; g < hi; ++g) {
+                const uint32_t v = tmp[c * TKF_STRIDE + (g - P[c])];
+                if (v != TKF_HOLE) out_ids[t++] = v;
+            }
             ++c;
         }
         if (add_eos) out_ids[t++] = T.eos_id;

@@ -70,20 +70,16 @@ TK_DEV uint32_t tk_uc_class(const TkTablesView& t, uint32_t cp) {
 
 struct alignas(16) tk_u32x4 { uint32_t x, y, z, w; };
 
-// One probe = ONE round trip: the 32-byte entry is fetched with two 16-byte loads issued together and
-// compared with bitwise ops (a short-circuit && chain compiles to one dependent load per field).
+// One probe = ONE round trip: both candidate entries (cuckoo, tk_hash.h) are fetched together with 16-byte loads
+// and compared with bitwise ops; there is no probe loop.
 TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
-    uint32_t s = tk_key_hash(k0, k1, k2, k3, len) & t.key_mask;
-    for (uint32_t tries = 0; tries <= t.key_mask; ++tries) {  // load factor <= 1/2: an empty slot is always met
-        const tk_u32x4* e = reinterpret_cast<const tk_u32x4*>(t.key_tab + s);
-        const tk_u32x4 a = e[0], b = e[1];  // a = key, b = {rank, len, pad, pad}
-        const uint32_t diff = (a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len);
-        // one exit test on BOTH loads (an early `if (len == 0)` makes the compiler sink the key load behind it)
-        const uint32_t res = diff == 0u ? b.x : TK_RANK_MAX;
-        if ((res != TK_RANK_MAX) | (b.y == 0u)) return res;  // ranks are < 2^21, so MAX is never a rank
-        s = (s + 1u) & t.key_mask;
-    }
-    return TK_RANK_MAX;
+    const uint32_t h = tk_key_hash(k0, k1, k2, k3, len);
+    const tk_u32x4* e1 = reinterpret_cast<const tk_u32x4*>(t.key_tab + (h & t.key_mask));
+    const tk_u32x4* e2 = reinterpret_cast<const tk_u32x4*>(t.key_tab + (tk_hash_alt(h) & t.key_mask));
+    const tk_u32x4 a1 = e1[0], b1 = e1[1], a2 = e2[0], b2 = e2[1];  // a = key, b = {rank, len, pad, pad}
+    const uint32_t d1 = (a1.x ^ k0) | (a1.y ^ k1) | (a1.z ^ k2) | (a1.w ^ k3) | (b1.y ^ len);
+    const uint32_t d2 = (a2.x ^ k0) | (a2.y ^ k1) | (a2.z ^ k2) | (a2.w ^ k3) | (b2.y ^ len);
+    return d1 == 0u ? b1.x : d2 == 0u ? b2.x : TK_RANK_MAX;       // an empty entry has len 0, a probed key len >= 2
 }
 
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so
@@ -104,35 +100,28 @@ TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, u
     return TK_RANK_MAX;
 }
 
+struct alignas(16) tk_u64x2 { uint64_t x, y; };
+
+// PAIR: two buckets of two entries, fetched together (one 16-byte load each); an empty entry is all ones and
+// matches no key (ids are < 2^21)
 TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
-    uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
-    uint32_t s = tk_pair_hash(a, b) & t.pair_mask;
-    for (uint32_t tries = 0; tries <= t.pair_mask; ++tries) {
-        uint64_t e = t.pair_tab[s];
-        if (e == TK_PAIR_EMPTY) return TK_RANK_MAX;
-        if (tk_pair_key(e) == key) return tk_pair_rank(e);
-        s = (s + 1u) & t.pair_mask;
-    }
-    return TK_RANK_MAX;
+    const uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
+    const uint32_t h = tk_pair_hash(a, b);
+    const tk_u64x2 p = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h & t.pair_mask));
+    const tk_u64x2 q = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h) & t.pair_mask));
+    uint32_t r = TK_RANK_MAX;
+    if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
+    if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
+    if (tk_pair_key(q.x) == key) r = tk_pair_rank(q.x);
+    if (tk_pair_key(q.y) == key) r = tk_pair_rank(q.y);
+    return r;
 }
 
-// two independent PAIR probes whose first-slot loads are issued together (one round trip for both)
+// two independent PAIR probes: all four bucket loads are in flight together
 TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t& r0,
                              uint32_t& r1) {
-    const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
-    uint32_t s0 = tk_pair_hash(a0, b0) & t.pair_mask, s1 = tk_pair_hash(a1, b1) & t.pair_mask;
-    uint64_t e0 = t.pair_tab[s0], e1 = t.pair_tab[s1];
-    r0 = TK_RANK_MAX;
-    r1 = TK_RANK_MAX;
-    for (uint32_t tries = 0; tries <= t.pair_mask; ++tries) {
-        const bool done0 = (e0 == TK_PAIR_EMPTY) | (tk_pair_key(e0) == key0);
-        const bool done1 = (e1 == TK_PAIR_EMPTY) | (tk_pair_key(e1) == key1);
-        if (done0 & done1) break;
-        if (!done0) { s0 = (s0 + 1u) & t.pair_mask; e0 = t.pair_tab[s0]; }
-        if (!done1) { s1 = (s1 + 1u) & t.pair_mask; e1 = t.pair_tab[s1]; }
-    }
-    if (e0 != TK_PAIR_EMPTY && tk_pair_key(e0) == key0) r0 = tk_pair_rank(e0);
-    if (e1 != TK_PAIR_EMPTY && tk_pair_key(e1) == key1) r1 = tk_pair_rank(e1);
+    r0 = tk_probe_pair(t, a0, b0);
+    r1 = tk_probe_pair(t, a1, b1);
 }
 
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {

@@ -45,11 +45,8 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {
-    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKM_LDS_WORDS];
-    const int lane = wv_lane();
-    uint32_t* lds = lds_all + (threadIdx.x >> 6) * TKM_LDS_WORDS;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    tk_merge_wave(a, wave, lane, lds);
+    tk_merge_wave(a, wave, wv_lane());
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
@@ -73,27 +70,52 @@ __device__ __forceinline__ uint64_t tkf_G(const uint64_t* doc_offs, uint64_t i, 
     return P[p / TKF_COMMIT] + lstart[i];
 }
 
+// per document: where its id slots start in the chunk-dense buffer, how many there are (holes included) and how many of
+// them lie in the first chunk -- everything tk_flat_assemble_kernel needs in one 16-byte load
+struct alignas(16) TkFlatDocInfo {
+    uint64_t src;      // index into tmp (or into the per-document kernel's staging for a handed-back document)
+    uint32_t n_slots;  // slots to walk (handed-back document: ids to copy)
+    uint32_t n_first;  // slots in the first chunk; 0xFFFFFFFF marks a handed-back document
+};
+
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
                                                                     uint64_t n_bytes, uint64_t n_chunks,
                                                                     const uint64_t* __restrict__ P,
                                                                     const uint32_t* __restrict__ lstart,
                                                                     const uint32_t* __restrict__ flags,
                                                                     const uint32_t* __restrict__ holes, uint32_t extra,
-                                                                    uint32_t* __restrict__ counts) {
+                                                                    uint32_t* __restrict__ counts,
+                                                                    TkFlatDocInfo* __restrict__ info) {
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
-    if (d >= n_docs || flags[d]) return;  // a flagged document keeps the count of the per-document kernel
+    if (d >= n_docs) return;
+    TkFlatDocInfo di;
+    if (flags[d]) {  // a flagged document keeps the count of the per-document kernel
+        di.src = doc_offs[d] + 2 * d;
+        di.n_slots = counts[d];
+        di.n_first = 0xFFFFFFFFu;
+        info[d] = di;
+        return;
+    }
     const uint64_t g0 = tkf_G(doc_offs, d, n_bytes, n_chunks, P, lstart);
     const uint64_t g1 = tkf_G(doc_offs, d + 1, n_bytes, n_chunks, P, lstart);
     counts[d] = (uint32_t)(g1 - g0) - holes[d] + extra;
+    const uint64_t p = doc_offs[d];
+    di.src = 0;
+    di.n_slots = (uint32_t)(g1 - g0);
+    di.n_first = 0;
+    if (p < n_bytes) {
+        const uint64_t c = p / TKF_COMMIT;
+        const uint64_t in_chunk = P[c + 1] - g0;  // slots of chunk c from the document start on
+        di.src = c * TKF_STRIDE + lstart[d];
+        di.n_first = (uint32_t)(in_chunk < (g1 - g0) ? in_chunk : (g1 - g0));
+    }
+    info[d] = di;
 }
 
 struct TkFlatAssembleArgs {
-    const uint64_t* doc_offs;
-    uint64_t n_docs, n_bytes, n_chunks;
-    const uint64_t* P;
-    const uint32_t* lstart;
-    const uint32_t* flags;
-    const uint32_t* counts;
+    uint64_t n_docs;
+    const TkFlatDocInfo* info;
+    const uint32_t* kcount;
     const uint64_t* out_offs;
     const uint32_t* tmp;
     const uint32_t* staging;  // per-document kernel output (document d at doc_offs[d] + 2 d), flagged documents only
@@ -107,37 +129,36 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
     for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
+        const TkFlatDocInfo di = a.info[d];
         uint32_t* dst = a.out_ids + a.out_offs[d];
-        if (a.flags[d]) {
-            const uint32_t cnt = a.counts[d];
-            const uint32_t* src = a.staging + a.doc_offs[d] + 2 * d;
-            for (uint32_t k = (uint32_t)lane; k < cnt; k += 64u) dst[k] = src[k];
+        if (di.n_first == 0xFFFFFFFFu) {
+            const uint32_t* src = a.staging + di.src;
+            for (uint32_t k = (uint32_t)lane; k < di.n_slots; k += 64u) dst[k] = src[k];
             continue;
         }
-        const uint64_t g0 = tkf_G(a.doc_offs, d, a.n_bytes, a.n_chunks, a.P, a.lstart);
-        const uint64_t g1 = tkf_G(a.doc_offs, d + 1, a.n_bytes, a.n_chunks, a.P, a.lstart);
         if (a.add_bos) {
             if (lane == 0) dst[0] = a.bos_id;
             dst += 1;
         }
-        uint64_t g = g0;
-        uint64_t c = a.doc_offs[d] / TKF_COMMIT;
-        while (g < g1) {  // slots [g, g1) live chunk-dense: slot g of chunk c at tmp[c * STRIDE + g - P[c]]; holes are skipped
-            const uint64_t pc = a.P[c], pn = a.P[c + 1];
-            const uint64_t hi = g1 < pn ? g1 : pn;
-            if (hi > g) {
-                const uint32_t* src = a.tmp + c * TKF_STRIDE + (g - pc);
-                const uint32_t nn = (uint32_t)(hi - g);
-                for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
-                    const uint32_t k = k0 + (uint32_t)lane;
-                    const uint32_t v = k < nn ? src[k] : TKF_HOLE;
-                    const uint64_t keep = __ballot(v != TKF_HOLE);
-                    if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
-                    dst += __builtin_popcountll(keep);
-                }
-                g = hi;
+        // the document's slots: n_first in its first chunk, then whole chunks (slot 0 on) until n_slots are walked;
+        // holes (slots a missed piece reserved and did not need) are skipped
+        uint32_t left = di.n_slots, nn = di.n_first;
+        uint64_t c = di.src / TKF_STRIDE;
+        const uint32_t* src = a.tmp + di.src;
+        while (left) {
+            for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                const uint32_t v = k < nn ? src[k] : TKF_HOLE;
+                const uint64_t keep = __ballot(v != TKF_HOLE);
+                if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
+                dst += __builtin_popcountll(keep);
             }
+            left -= nn;
+            if (left == 0) break;
             ++c;
+            const uint32_t kc = a.kcount[c];
+            nn = left < kc ? left : kc;
+            src = a.tmp + c * TKF_STRIDE;
         }
         if (a.add_eos && lane == 0) dst[0] = a.eos_id;
     }
@@ -165,9 +186,9 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
-    if (a.n_chunks == 0) return hipSuccess;
-    const uint64_t waves = (a.n_chunks + TKM_GROUP - 1) / TKM_GROUP;
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss, hipStream_t s) {
+    if (n_miss == 0) return hipSuccess;
+    const uint64_t waves = (n_miss + 63) / 64;
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((waves + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
@@ -180,25 +201,23 @@ hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t*
 
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
                                  const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,
-                                 uint32_t extra, uint32_t* counts, hipStream_t s) {
+                                 uint32_t extra, uint32_t* counts, void* doc_info, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_flat_counts_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs, n_bytes,
-                       n_chunks, P, lstart, flags, holes, extra, counts);
+                       n_chunks, P, lstart, flags, holes, extra, counts, (TkFlatDocInfo*)doc_info);
     return hipGetLastError();
 }
 
-hipError_t tk_launch_flat_assemble(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
-                                   const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* counts,
-                                   const uint64_t* out_offs, const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids,
-                                   uint32_t bos_id, uint32_t eos_id, int add_bos, int add_eos, hipStream_t s) {
+hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
+                                   const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
+                                   uint32_t eos_id, int add_bos, int add_eos, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     TkFlatAssembleArgs a;
-    a.doc_offs = doc_offs; a.n_docs = n_docs; a.n_bytes = n_bytes; a.n_chunks = n_chunks;
-    a.P = P; a.lstart = lstart; a.flags = flags; a.counts = counts; a.out_offs = out_offs;
+    a.n_docs = n_docs; a.info = (const TkFlatDocInfo*)doc_info; a.kcount = kcount; a.out_offs = out_offs;
     a.tmp = tmp; a.staging = staging; a.out_ids = out_ids;
     a.bos_id = bos_id; a.eos_id = eos_id; a.add_bos = add_bos; a.add_eos = add_eos;
     uint64_t blocks = (n_docs + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tk_flat_assemble_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }

@@ -456,94 +456,133 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 // tk_merge_wave: byte-pair merge of 64 queued pieces, ONE LANE PER PIECE (tiktoken's _byte_pair_merge,
 // repeatedly merge the leftmost minimum-rank adjacent pair).  Every lane runs its own
 // chain of dependent PAIR probes, 64 chains per wave and many waves per SIMD hide their latency.
-// Pieces of up to TKM_SHORT bytes keep their parts in LDS ([part][lane], conflict-free); the rare longer
+// Pieces of up to TKM_SHORT bytes keep their parts in registers; the rare longer
 // ones (<= 64 bytes) are merged one at a time, one lane per byte, with the segmented-min rounds.
 // The ids go to the `len` slots the flat kernel reserved; unused slots become TKF_HOLE and the
 // document's hole count is raised so that tk_flat_counts / assemble can squeeze them out.
 // ------------------------------------------------------------------------------------------
 #define TKM_SHORT 16
-#define TKM_LDS_WORDS (2 * TKM_SHORT * 64)
 
-#define TKM_GROUP 16 /* chunks whose queues one wave takes */
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane);
 
-TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* lds);
-
-TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* lds) {
-    // the queues of TKM_GROUP consecutive chunks, 64 pieces at a time
-    const uint64_t cbase = wave_id * TKM_GROUP;
-    uint32_t cnt = 0;
-    if (lane < TKM_GROUP && cbase + (uint64_t)lane < a.n_chunks) cnt = a.miss_count[cbase + lane];
-    uint32_t total;
-    const uint32_t excl = tkf_scan_excl(cnt, lane, &total);
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t item = base + (uint32_t)lane;
-        // chunk of the item: the last queue whose first item is <= item
-        uint32_t k = 0, first = 0;
-        for (int q = 1; q < TKM_GROUP; ++q) {
-            const uint32_t eq = wv_readlane(excl, q), nq = wv_readlane(cnt, q);
-            if (nq != 0u && eq <= item) { k = (uint32_t)q; first = eq; }
-        }
-        const bool have = item < total;
-        uint32_t rec = 0;
-        if (have) rec = a.miss_list[(cbase + k) * TKF_MISSCAP + (item - first)];
-        tk_merge_items(a, have, rec, (uint32_t)(cbase + k), lane, lds);
+// 64 queued pieces per wave: item i of the global queue order lives in the queue of the chunk c with
+// miss_prefix[c] <= i < miss_prefix[c + 1] (exclusive prefix sums of miss_count, total at [n_chunks]).
+TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
+    const uint64_t total = a.miss_prefix[a.n_chunks];
+    const uint64_t item0 = wave_id * 64;
+    if (item0 >= total) return;                       // wave-uniform
+    // chunk of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
+    uint64_t lo = 0, hi = a.n_chunks;                 // invariant: prefix[lo] <= item0 < prefix[hi]
+    while (hi - lo > 1) {
+        const uint64_t step = (hi - lo + 63) / 64;
+        const uint64_t q = lo + (uint64_t)lane * step;
+        const bool le = q < hi && a.miss_prefix[q] <= item0;
+        const uint64_t LE = wv_ballot(le);            // a prefix of the lanes (lane 0 always)
+        const int top = tk_msb64(LE);
+        const uint64_t nlo = lo + (uint64_t)top * step;
+        const uint64_t nhi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo;
+        hi = nhi;
     }
+    // every lane: the chunk of its own item, searched from the wave's first chunk on
+    const uint64_t item = item0 + (uint64_t)lane;
+    const bool have = item < total;
+    uint64_t cl = lo, ch = lo + 64 < a.n_chunks ? lo + 64 : a.n_chunks;   // prefix[cl] <= item < prefix[ch]
+    if (have) {
+        while (a.miss_prefix[ch] <= item) {           // never past n_chunks: prefix[n_chunks] = total > item
+            cl = ch;
+            ch = ch + 64 < a.n_chunks ? ch + 64 : a.n_chunks;
+        }
+        while (ch - cl > 1) {
+            const uint64_t mid = (cl + ch) / 2;
+            if (a.miss_prefix[mid] <= item) cl = mid; else ch = mid;
+        }
+    }
+    uint32_t rec = 0;
+    if (have) rec = a.miss_list[cl * TKF_MISSCAP + (item - a.miss_prefix[cl])];
+    tk_merge_items(a, have, rec, (uint32_t)cl, lane);
 }
 
-TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* lds) {
-    const TkTablesView& t = a.t;
-    const uint32_t pos = rec & 1023u, len = (rec >> 10) & 127u, slot = rec >> 17;
-    const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
-    uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
-    uint32_t* tokL = lds;                       // [TKM_SHORT][64]
-    uint32_t* prkL = lds + TKM_SHORT * 64;      // [TKM_SHORT][64]
-    uint32_t holes = 0;
-
-    // ---- short pieces: sequential merge per lane ----------------------------------------------------
-    const bool isshort = have && len <= TKM_SHORT;
-    uint32_t np = isshort ? len : 0u;
-    if (isshort) {
-        uint32_t prev = a.bytes[g];
-        for (uint32_t i = 0; i < np; ++i) {
-            const uint32_t nxt = i + 1 < np ? (uint32_t)a.bytes[g + i + 1] : 0u;
-            tokL[i * 64 + lane] = prev;
-            prkL[i * 64 + lane] = i + 1 < np ? t.pair2[prev | (nxt << 8)] : TK_RANK_MAX;
-            prev = nxt;
-        }
+// sequential merge of one piece per lane, parts in registers: N-wide arrays, every loop unrolled so that they are
+// only ever indexed statically; predication does the rest.  `kk` = the piece bytes, np = number of bytes.
+template <int N>
+TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* kk, uint32_t len, uint32_t* out) {
+    uint32_t np = mine ? len : 0u;
+    uint32_t tk[N], pr[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) tk[i] = (kk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        pr[i] = TK_RANK_MAX;
+        if (i + 1 < N && (uint32_t)(i + 1) < np) pr[i] = t.pair2[tk[i] | (tk[(i + 1) & (N - 1)] << 8)];
     }
-    bool active = isshort;
+    bool active = mine;
     while (wv_ballot(active)) {
         if (active) {
+            // leftmost minimum; pr[i] == MAX for i >= np - 1 is an invariant
             uint32_t best = TK_RANK_MAX, bi = 0;
-            for (uint32_t i = 0; i + 1 < np; ++i) {
-                const uint32_t rk = prkL[i * 64 + lane];
-                if (rk < best) { best = rk; bi = i; }
+#pragma unroll
+            for (int i = 0; i < N - 1; ++i) {
+                if (pr[i] < best) { best = pr[i]; bi = (uint32_t)i; }
             }
             if (best == TK_RANK_MAX) {
                 active = false;
             } else {
                 // parts bi and bi + 1 become one part whose id is the rank of the pair
-                for (uint32_t i = bi + 1; i + 1 < np; ++i) {
-                    tokL[i * 64 + lane] = tokL[(i + 1) * 64 + lane];
-                    prkL[i * 64 + lane] = prkL[(i + 1) * 64 + lane];
+                uint32_t tn = 0, tp = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    if ((uint32_t)i == bi + 2u) tn = tk[i];
+                    if ((uint32_t)i + 1u == bi) tp = tk[i];
                 }
+#pragma unroll
+                for (int i = 0; i < N - 1; ++i) {
+                    if ((uint32_t)i > bi) { tk[i] = tk[i + 1]; pr[i] = pr[i + 1]; }
+                }
+                pr[N - 1] = TK_RANK_MAX;
                 np -= 1;
-                tokL[bi * 64 + lane] = best;
                 const bool has_next = bi + 1 < np, has_prev = bi > 0;
-                const uint32_t tn = has_next ? tokL[(bi + 1) * 64 + lane] : 0u;
-                const uint32_t tp = has_prev ? tokL[(bi - 1) * 64 + lane] : 0u;
                 uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
                 if (has_next && has_prev) tk_probe_pair_x2(t, best, tn, tp, best, r_next, r_prev);
                 else if (has_next) r_next = tk_probe_pair(t, best, tn);
                 else if (has_prev) r_prev = tk_probe_pair(t, tp, best);
-                prkL[bi * 64 + lane] = r_next;
-                if (has_prev) prkL[(bi - 1) * 64 + lane] = r_prev;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    if ((uint32_t)i == bi) { tk[i] = best; pr[i] = r_next; }
+                    if ((uint32_t)i + 1u == bi) pr[i] = r_prev;
+                }
             }
         }
     }
-    if (isshort) {
-        for (uint32_t i = 0; i < len; ++i) out[i] = i < np ? tokL[i * 64 + lane] + t.num_special : TKF_HOLE;
-        holes = len - np;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((uint32_t)i < len) out[i] = (uint32_t)i < np ? tk[i] + t.num_special : TKF_HOLE;
+    }
+    return mine ? len - np : 0u;
+}
+
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane) {
+    const TkTablesView& t = a.t;
+    const uint32_t pos = rec & 1023u, len = (rec >> 10) & 127u, slot = rec >> 17;
+    const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
+    uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
+    uint32_t holes = 0;
+
+    // ---- short pieces (<= 16 bytes): one lane each; the <= 8-byte ones run the 8-wide variant ---------
+    {
+        const bool isshort = have && len <= TKM_SHORT;
+        uint32_t kk[4] = {0u, 0u, 0u, 0u};
+        if (isshort) {
+            if (g + 16 <= (int64_t)a.n_bytes) {
+                wv_load16(a.bytes + g, kk);
+            } else {
+                for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)a.bytes[g + q] << (8 * (q & 3));
+            }
+        }
+        const bool s8 = isshort && len <= 8u, s16 = isshort && len > 8u;
+        if (wv_ballot(s8)) holes += tk_merge_regs<8>(t, s8, kk, len, out);
+        if (wv_ballot(s16)) holes += tk_merge_regs<16>(t, s16, kk, len, out);
     }
 
     // ---- long pieces (17..64 bytes): one at a time, one lane per byte ----------------------------------

@@ -10,6 +10,12 @@
 //   PAIR2  direct 64K table for two single bytes                         -> rank
 //
 // KEY/LONG serve the whole-piece shortcut, PAIR/PAIR2 serve the merge loop.
+//
+// KEY and PAIR are CUCKOO tables: every key has exactly two candidate locations (slot / bucket h & mask and
+// rotl(h, 16) & mask), both are fetched together, so a probe is ONE round trip whether it hits or misses --
+// no probe loop, no divergence between the 64 lanes of a wave (with linear probing the wave waited for its
+// longest chain of dependent loads).  KEY: one 32-byte entry per slot, load <= 1/3.  PAIR: buckets of two
+// 8-byte entries (one 16-byte load per bucket), load <= 1/2.
 #ifndef TK_HASH_H
 #define TK_HASH_H
 #include <stdint.h>
@@ -59,6 +65,8 @@ TK_HD uint32_t tk_long_hash(uint32_t h1, uint32_t len) {
 TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
     return tk_fmix32(a * 0x9E3779B1u + b * 0x85EBCA77u + 0x165667B1u);
 }
+
+TK_HD uint32_t tk_hash_alt(uint32_t h) { return (h << 16) | (h >> 16); }  /* second location: the other half of the bits */
 
 TK_HD uint64_t tk_pair_pack(uint32_t a, uint32_t b, uint32_t rank) {
     return ((uint64_t)a << (2 * TK_ID_BITS)) | ((uint64_t)b << TK_ID_BITS) | (uint64_t)rank;

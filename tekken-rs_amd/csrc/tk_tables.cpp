@@ -6,6 +6,7 @@
 
 #include <string>
 #include <unordered_map>
+#include <utility>
 
 #include "../../include/tekken_hip.h"
 #include "unicode_tables.h"
@@ -103,10 +104,10 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
     }
     out.n_key = n_key;
     out.n_long = n_long;
-    uint32_t kcap = pow2_at_least(2 * n_key + 1), lcap = pow2_at_least(2 * n_long + 1);
-    out.key_mask = kcap - 1;
+    uint32_t lcap = pow2_at_least(2 * n_long + 1);
     out.long_mask = lcap - 1;
-    out.key_tab.assign(kcap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
+    std::vector<tk_key_entry> key_entries;
+    key_entries.reserve(n_key);
     out.long_tab.assign(lcap, tk_long_entry{0, 0, 0, 0});
     out.pair2.assign(65536, TK_RANK_MAX);
 
@@ -117,9 +118,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         if (len >= 2 && len <= 16) {
             uint32_t k[4] = {0, 0, 0, 0};
             for (uint32_t j = 0; j < len; ++j) k[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
-            uint32_t s = tk_key_hash(k[0], k[1], k[2], k[3], len) & out.key_mask;
-            while (out.key_tab[s].len) s = (s + 1) & out.key_mask;
-            out.key_tab[s] = tk_key_entry{{k[0], k[1], k[2], k[3]}, r, len, {0, 0}};
+            key_entries.push_back(tk_key_entry{{k[0], k[1], k[2], k[3]}, r, len, {0, 0}});
         } else if (len >= 17) {
             uint32_t h1 = 0, h2 = 0;
             for (uint32_t k = 0; k < len; ++k) {
@@ -130,6 +129,34 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
             while (out.long_tab[s].len) s = (s + 1) & out.long_mask;
             out.long_tab[s] = tk_long_entry{h2, r, len, offs[r]};
         }
+    }
+
+    // KEY: cuckoo placement, one entry per slot, two candidate slots per key, load <= 1/3 (grown on failure)
+    for (uint32_t kcap = pow2_at_least(3 * n_key + 1);; kcap <<= 1) {
+        out.key_mask = kcap - 1;
+        out.key_tab.assign(kcap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
+        bool ok = true;
+        uint32_t rnd = 0x9E3779B9u;
+        for (const tk_key_entry& e0 : key_entries) {
+            tk_key_entry e = e0;
+            uint32_t avoid = 0xFFFFFFFFu;
+            int kicks = 0;
+            for (;; ++kicks) {
+                const uint32_t h = tk_key_hash(e.k[0], e.k[1], e.k[2], e.k[3], e.len);
+                const uint32_t s1 = h & out.key_mask, s2 = tk_hash_alt(h) & out.key_mask;
+                if (out.key_tab[s1].len == 0) { out.key_tab[s1] = e; break; }
+                if (out.key_tab[s2].len == 0) { out.key_tab[s2] = e; break; }
+                if (kicks >= 500) { ok = false; break; }
+                rnd = rnd * 1664525u + 1013904223u;
+                uint32_t victim = (rnd >> 16) & 1u ? s2 : s1;
+                if (victim == avoid) victim = victim == s1 ? s2 : s1;   // do not bounce straight back
+                std::swap(e, out.key_tab[victim]);
+                avoid = victim;
+            }
+            if (!ok) break;
+        }
+        if (ok) break;
+        if (kcap >= (1u << 30)) { err = "could not place the vocabulary in the KEY table"; return TK_ERR_INVALID_CONFIG; }
     }
 
     // PAIR: every split of every token whose halves are both tokens
@@ -150,15 +177,37 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         }
     }
     out.n_pairs = pairs.size();
-    uint32_t pcap = pow2_at_least(2 * pairs.size() + 1);
-    out.pair_mask = pcap - 1;
-    out.pair_tab.assign(pcap, TK_PAIR_EMPTY);
-    for (uint64_t e : pairs) {
-        uint64_t key = tk_pair_key(e);
-        uint32_t ida = (uint32_t)(key >> TK_ID_BITS), idb = (uint32_t)(key & ((1u << TK_ID_BITS) - 1u));
-        uint32_t s = tk_pair_hash(ida, idb) & out.pair_mask;
-        while (out.pair_tab[s] != TK_PAIR_EMPTY) s = (s + 1) & out.pair_mask;
-        out.pair_tab[s] = e;
+    // cuckoo placement: buckets of two entries, two candidate buckets per pair, load <= 1/2 (grown on failure)
+    for (uint32_t nb = pow2_at_least(pairs.size() + 1);; nb <<= 1) {
+        out.pair_mask = nb - 1;
+        out.pair_tab.assign((size_t)nb * 2, TK_PAIR_EMPTY);
+        bool ok = true;
+        uint32_t rnd = 0x85EBCA6Bu;
+        for (uint64_t e0 : pairs) {
+            uint64_t e = e0;
+            uint64_t avoid = ~0ull;
+            int kicks = 0;
+            for (;; ++kicks) {
+                const uint64_t key = tk_pair_key(e);
+                const uint32_t ida = (uint32_t)(key >> TK_ID_BITS), idb = (uint32_t)(key & ((1u << TK_ID_BITS) - 1u));
+                const uint32_t h = tk_pair_hash(ida, idb);
+                const uint64_t b1 = 2ull * (h & out.pair_mask), b2 = 2ull * (tk_hash_alt(h) & out.pair_mask);
+                const uint64_t cand[4] = {b1, b1 + 1, b2, b2 + 1};
+                bool placed = false;
+                for (uint64_t sl : cand)
+                    if (out.pair_tab[sl] == TK_PAIR_EMPTY) { out.pair_tab[sl] = e; placed = true; break; }
+                if (placed) break;
+                if (kicks >= 500) { ok = false; break; }
+                rnd = rnd * 1664525u + 1013904223u;
+                uint64_t victim = cand[(rnd >> 16) & 3u];
+                if (victim == avoid) victim = cand[((rnd >> 16) + 1u) & 3u];
+                std::swap(e, out.pair_tab[victim]);
+                avoid = victim;
+            }
+            if (!ok) break;
+        }
+        if (ok) break;
+        if (nb >= (1u << 30)) { err = "could not place the vocabulary in the PAIR table"; return TK_ERR_INVALID_CONFIG; }
     }
     return TK_OK;
 }

@@ -17,9 +17,9 @@
 struct TkTablesView {
     const uint16_t* uc_stage1;       // Unicode class trie, stage 1 (cp >> 7 -> block)
     const uint32_t* uc_stage2;       // stage 2: 16 x 2-bit classes per word
-    const tk_key_entry* key_tab;     // whole pieces of 2..16 bytes (exact key)
+    const tk_key_entry* key_tab;     // whole pieces of 2..16 bytes (exact key), cuckoo: slots h & key_mask, alt(h) & key_mask
     const tk_long_entry* long_tab;   // whole pieces of >= 17 bytes
-    const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21
+    const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
     const uint8_t* blob;             // token bytes, for verifying LONG hits
     uint32_t key_mask, long_mask, pair_mask;

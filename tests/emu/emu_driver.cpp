@@ -132,9 +132,11 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
         });
         ops += tkemu::g_wave->n_ops;
-        std::vector<uint32_t> mlds(TKM_LDS_WORDS, 0);
-        for (uint64_t w = 0; w * TKM_GROUP < n_chunks; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave(fa, w, lane, mlds.data()); });
+        std::vector<uint64_t> mpfx(n_chunks + 1, 0);
+        for (uint64_t c = 0; c < n_chunks; ++c) mpfx[c + 1] = mpfx[c] + miss_count[c];
+        fa.miss_prefix = mpfx.data();
+        for (uint64_t w = 0; w * 64 < mpfx[n_chunks]; ++w) {
+            tkemu::run_wave([&](int lane) { tk_merge_wave(fa, w, lane); });
             ops += tkemu::g_wave->n_ops;
         }
     }

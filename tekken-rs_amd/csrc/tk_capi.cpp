@@ -57,7 +57,7 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
-    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_holes, f_info;  // flat path (tk_flat.hip)
+    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_mcnt_b, f_mpfx_b, f_holes, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
     uint64_t n_flagged = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -163,7 +163,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
-                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_holes, &c->f_info};
+                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_mcnt_b, &c->f_mpfx_b, &c->f_holes, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -288,6 +288,8 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, c->f_miss.reserve((n_chunks * TKF_MISSCAP + 64) * 4));  // worst case; only the used records are ever touched
     TK_HIP(c, c->f_mcnt.reserve((n_chunks + 1) * 4));
     TK_HIP(c, c->f_mpfx.reserve((n_chunks + 2) * 8));
+    TK_HIP(c, c->f_mcnt_b.reserve((n_chunks + 1) * 4));
+    TK_HIP(c, c->f_mpfx_b.reserve((n_chunks + 2) * 8));
     TK_HIP(c, c->f_holes.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->f_info.reserve((n_docs + 1) * 16));
     TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
@@ -310,6 +312,8 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.miss_list = (uint32_t*)c->f_miss.p;
     fa.miss_count = (uint32_t*)c->f_mcnt.p;
     fa.miss_prefix = (const uint64_t*)c->f_mpfx.p;
+    fa.miss_count_b = (uint32_t*)c->f_mcnt_b.p;
+    fa.miss_prefix_b = (const uint64_t*)c->f_mpfx_b.p;
     fa.holes = (uint32_t*)c->f_holes.p;
     fa.t = c->dview;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
@@ -324,13 +328,15 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, hipEventRecord(c->ev[1], s));
     TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
     TK_HIP(c, tk_launch_scan(fa.miss_count, n_chunks, (uint64_t*)c->f_mpfx.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_scan(fa.miss_count_b, n_chunks, (uint64_t*)c->f_mpfx_b.p, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_scan(fa.kcount, n_chunks, (uint64_t*)c->f_P.p, (uint64_t*)c->block_sums.p, s));
     uint32_t n_todo = 0;
-    uint64_t n_miss = 0;
+    uint64_t n_miss_a = 0, n_miss_b = 0;
     TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(&n_miss, (uint64_t*)c->f_mpfx.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&n_miss_a, (uint64_t*)c->f_mpfx.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&n_miss_b, (uint64_t*)c->f_mpfx_b.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
     TK_HIP(c, hipStreamSynchronize(s));
-    TK_HIP(c, tk_launch_merge(fa, n_miss, s));
+    TK_HIP(c, tk_launch_merge(fa, n_miss_a, n_miss_b, s));
     c->n_flagged = n_todo;
     c->n_long_docs = 0;
     if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,

@@ -75,7 +75,8 @@ __device__ __forceinline__ uint64_t tkf_G(const uint64_t* doc_offs, uint64_t i, 
 struct alignas(16) TkFlatDocInfo {
     uint64_t src;      // index into tmp (or into the per-document kernel's staging for a handed-back document)
     uint32_t n_slots;  // slots to walk (handed-back document: ids to copy)
-    uint32_t n_first;  // slots in the first chunk; 0xFFFFFFFF marks a handed-back document
+    uint32_t n_first;  // slots in the first chunk; bit 31: not eligible for the two-segment fast copy; 0xFFFFFFFF marks a
+                       // handed-back document
 };
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_
         const uint64_t in_chunk = P[c + 1] - g0;  // slots of chunk c from the document start on
         di.src = c * TKF_STRIDE + lstart[d];
         di.n_first = (uint32_t)(in_chunk < (g1 - g0) ? in_chunk : (g1 - g0));
+        // the assembly's prefetching copy takes documents of <= 128 slots that lie in at most two chunks
+        const uint64_t rest = (g1 - g0) - di.n_first;
+        if ((g1 - g0) > 128 || (rest && rest > P[c + 2] - P[c + 1])) di.n_first |= 0x80000000u;
     }
     info[d] = di;
 }
@@ -124,43 +128,108 @@ struct TkFlatAssembleArgs {
     int add_bos, add_eos;
 };
 
+// generic copy of one document (any number of chunks / slots, or a handed-back document)
+__device__ __forceinline__ void tkf_assemble_doc(const TkFlatAssembleArgs& a, const TkFlatDocInfo& di0, uint32_t* dst, int lane) {
+    TkFlatDocInfo di = di0;
+    if (di.n_first == 0xFFFFFFFFu) {
+        const uint32_t* src = a.staging + di.src;
+        for (uint32_t k = (uint32_t)lane; k < di.n_slots; k += 64u) dst[k] = src[k];
+        return;
+    }
+    di.n_first &= 0x7FFFFFFFu;
+    if (a.add_bos) {
+        if (lane == 0) dst[0] = a.bos_id;
+        dst += 1;
+    }
+    // the document's slots: n_first in its first chunk, then whole chunks (slot 0 on) until n_slots are walked;
+    // holes (slots a missed piece reserved and did not need) are skipped
+    uint32_t left = di.n_slots, nn = di.n_first;
+    uint64_t c = di.src / TKF_STRIDE;
+    const uint32_t* src = a.tmp + di.src;
+    while (left) {
+        for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            const uint32_t v = k < nn ? src[k] : TKF_HOLE;
+            const uint64_t keep = __ballot(v != TKF_HOLE);
+            if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
+            dst += __builtin_popcountll(keep);
+        }
+        left -= nn;
+        if (left == 0) break;
+        ++c;
+        const uint32_t kc = a.kcount[c];
+        nn = left < kc ? left : kc;
+        src = a.tmp + c * TKF_STRIDE;
+    }
+    if (a.add_eos && lane == 0) dst[0] = a.eos_id;
+}
+
+__device__ __forceinline__ uint32_t tkf_rl(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
+
+// One wave takes 64 consecutive documents: their 16-byte records and output offsets are fetched with one coalesced
+// load each (lane = document).  The documents are then copied EIGHT at a time: the 16 loads of a group (slots 0..63
+// and 64..127 of each document, across its chunk boundary) are issued back to back, so eight documents' worth of
+// HBM latency overlap; then each is squeezed (holes out) and stored with all 64 lanes.
+#define TKA_GROUP 8
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssembleArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
-    for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
-        const TkFlatDocInfo di = a.info[d];
-        uint32_t* dst = a.out_ids + a.out_offs[d];
-        if (di.n_first == 0xFFFFFFFFu) {
-            const uint32_t* src = a.staging + di.src;
-            for (uint32_t k = (uint32_t)lane; k < di.n_slots; k += 64u) dst[k] = src[k];
-            continue;
+    for (uint64_t d0 = wave * 64; d0 < a.n_docs; d0 += n_waves * 64) {
+        const uint64_t dm = d0 + (uint64_t)lane;
+        TkFlatDocInfo mine;
+        mine.src = 0; mine.n_slots = 0; mine.n_first = 0x80000000u;
+        uint64_t oo = 0;
+        if (dm < a.n_docs) {
+            mine = a.info[dm];
+            oo = a.out_offs[dm];
         }
-        if (a.add_bos) {
-            if (lane == 0) dst[0] = a.bos_id;
-            dst += 1;
-        }
-        // the document's slots: n_first in its first chunk, then whole chunks (slot 0 on) until n_slots are walked;
-        // holes (slots a missed piece reserved and did not need) are skipped
-        uint32_t left = di.n_slots, nn = di.n_first;
-        uint64_t c = di.src / TKF_STRIDE;
-        const uint32_t* src = a.tmp + di.src;
-        while (left) {
-            for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
-                const uint32_t k = k0 + (uint32_t)lane;
-                const uint32_t v = k < nn ? src[k] : TKF_HOLE;
-                const uint64_t keep = __ballot(v != TKF_HOLE);
-                if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
-                dst += __builtin_popcountll(keep);
+        const int nd = (int)(a.n_docs - d0 < 64 ? a.n_docs - d0 : 64);
+        const uint32_t src_lo = (uint32_t)mine.src, src_hi = (uint32_t)(mine.src >> 32);
+        const uint32_t oo_lo = (uint32_t)oo, oo_hi = (uint32_t)(oo >> 32);
+        for (int j0 = 0; j0 < nd; j0 += TKA_GROUP) {
+            uint32_t v0[TKA_GROUP], v1[TKA_GROUP];
+#pragma unroll
+            for (int g = 0; g < TKA_GROUP; ++g) {
+                const int j = j0 + g;                     // lanes beyond nd hold n_first = bit 31: skipped
+                v0[g] = TKF_HOLE; v1[g] = TKF_HOLE;
+                const uint32_t nf = tkf_rl(mine.n_first, j & 63);
+                if (!(nf & 0x80000000u)) {                // wave-uniform
+                    const uint32_t ns = tkf_rl(mine.n_slots, j & 63);
+                    const uint64_t src = ((uint64_t)tkf_rl(src_hi, j & 63) << 32) | tkf_rl(src_lo, j & 63);
+                    const uint64_t src2 = (src / TKF_STRIDE + 1) * TKF_STRIDE;   // slot 0 of the next chunk
+                    const uint32_t q0 = (uint32_t)lane, q1 = 64u + (uint32_t)lane;
+                    if (q0 < ns) v0[g] = q0 < nf ? a.tmp[src + q0] : a.tmp[src2 + (q0 - nf)];
+                    if (q1 < ns) v1[g] = q1 < nf ? a.tmp[src + q1] : a.tmp[src2 + (q1 - nf)];
+                }
             }
-            left -= nn;
-            if (left == 0) break;
-            ++c;
-            const uint32_t kc = a.kcount[c];
-            nn = left < kc ? left : kc;
-            src = a.tmp + c * TKF_STRIDE;
+#pragma unroll
+            for (int g = 0; g < TKA_GROUP; ++g) {
+                const int j = j0 + g;
+                if (j >= nd) break;
+                const uint32_t nf = tkf_rl(mine.n_first, j);
+                uint32_t* dst = a.out_ids + (((uint64_t)tkf_rl(oo_hi, j) << 32) | tkf_rl(oo_lo, j));
+                if (nf & 0x80000000u) {
+                    TkFlatDocInfo di;
+                    di.src = ((uint64_t)tkf_rl(src_hi, j) << 32) | tkf_rl(src_lo, j);
+                    di.n_slots = tkf_rl(mine.n_slots, j);
+                    di.n_first = nf;
+                    tkf_assemble_doc(a, di, dst, lane);
+                    continue;
+                }
+                if (a.add_bos) {
+                    if (lane == 0) dst[0] = a.bos_id;
+                    dst += 1;
+                }
+                const uint32_t c0 = v0[g], c1 = v1[g];
+                const uint64_t k0 = __ballot(c0 != TKF_HOLE), k1 = __ballot(c1 != TKF_HOLE);
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t n0 = (uint32_t)__builtin_popcountll(k0);
+                if (c0 != TKF_HOLE) dst[__builtin_popcountll(k0 & below)] = c0;
+                if (c1 != TKF_HOLE) dst[n0 + (uint32_t)__builtin_popcountll(k1 & below)] = c1;
+                if (a.add_eos && lane == 0) dst[n0 + (uint32_t)__builtin_popcountll(k1)] = a.eos_id;
+            }
         }
-        if (a.add_eos && lane == 0) dst[0] = a.eos_id;
     }
 }
 
@@ -186,9 +255,9 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss, hipStream_t s) {
-    if (n_miss == 0) return hipSuccess;
-    const uint64_t waves = (n_miss + 63) / 64;
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss_a, uint64_t n_miss_b, hipStream_t s) {
+    const uint64_t waves = (n_miss_a + 63) / 64 + (n_miss_b + 63) / 64;   // one class per wave, the short class first
+    if (waves == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((waves + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
@@ -216,7 +285,7 @@ hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const 
     a.n_docs = n_docs; a.info = (const TkFlatDocInfo*)doc_info; a.kcount = kcount; a.out_offs = out_offs;
     a.tmp = tmp; a.staging = staging; a.out_ids = out_ids;
     a.bos_id = bos_id; a.eos_id = eos_id; a.add_bos = add_bos; a.add_eos = add_eos;
-    uint64_t blocks = (n_docs + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
+    uint64_t blocks = ((n_docs + 63) / 64 + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);   // 64 documents per wave
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tk_flat_assemble_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();

@@ -21,9 +21,12 @@ struct TkFlatArgs {
     uint32_t* tmp;               // [n_chunks * TKF_STRIDE] chunk-dense ids
     uint32_t* kcount;            // [n_chunks] id slots of the chunk (holes included)
     uint32_t* lstart;            // [n_docs] id slots of the chunk before the document's first byte
-    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17
-    uint32_t* miss_count;        // [n_chunks] queued pieces of the chunk
-    const uint64_t* miss_prefix; // [n_chunks + 1] exclusive prefix sums of miss_count (the merge kernel's global item order)
+    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17;
+                                 // pieces of <= 8 bytes from the front of the chunk's region, longer ones from its back
+    uint32_t* miss_count;        // [n_chunks] queued pieces of <= 8 bytes
+    uint32_t* miss_count_b;      // [n_chunks] queued pieces of > 8 bytes
+    const uint64_t* miss_prefix; // [n_chunks + 1] exclusive prefix sums of miss_count (the merge kernel's item order, short class)
+    const uint64_t* miss_prefix_b;  // same for miss_count_b
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags

@@ -82,12 +82,9 @@ TK_DEV uint32_t tkf_ripple(uint32_t run, uint32_t seeds) {
 }
 
 TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
-    uint32_t x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = wv_shfl(x, lane >= d ? lane - d : lane);
-        if (lane >= d) x += o;
-    }
-    *total = wv_shfl(x, 63);
+    (void)lane;
+    const uint32_t x = wv_scan_incl_u32(v);
+    *total = wv_readlane(x, 63);
     return x - v;
 }
 
@@ -98,59 +95,47 @@ struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
 };
 
-// flags at bit 7 of every byte of y[0..3] (y[j] byte k = text byte 4k + j) -> 16-bit mask, bit 4k + j
-TK_DEV uint32_t tkf_gather(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    uint32_t c = ((f3 & 0x80808080u) | ((f2 >> 1) & 0x40404040u) | ((f1 >> 2) & 0x20202020u) | ((f0 >> 3) & 0x10101010u)) >> 4;
-    c = (c | (c >> 4)) & 0x00FF00FFu;
-    return (c | (c >> 8)) & 0xFFFFu;
+// 8x8 bit-matrix transpose of 8 bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte b holds bit b of every
+// input byte (bit i of the result byte = bit b of input byte i).  Three delta swaps (1x1 blocks inside 2x2,
+// 2x2 inside 4x4, 4x4 inside 8x8); the first two never cross the 32-bit halves.
+TK_DEV void tkf_transpose8(uint32_t& lo, uint32_t& hi) {
+    uint32_t t;
+    t = ((lo >> 7) ^ lo) & 0x00AA00AAu; lo ^= t ^ (t << 7);
+    t = ((hi >> 7) ^ hi) & 0x00AA00AAu; hi ^= t ^ (t << 7);
+    t = ((lo >> 14) ^ lo) & 0x0000CCCCu; lo ^= t ^ (t << 14);
+    t = ((hi >> 14) ^ hi) & 0x0000CCCCu; hi ^= t ^ (t << 14);
+    t = (((lo >> 28) | (hi << 4)) ^ lo) & 0xF0F0F0F0u;   // delta 28 across the halves
+    lo ^= t ^ (t << 28);
+    hi ^= t >> 4;
 }
 
-// per byte (all < 0x80 after masking): bit 7 set iff lo <= b <= hi
-TK_DEV uint32_t tkf_range(uint32_t x7, uint32_t lo, uint32_t hi) {
-    const uint32_t ge = x7 + (0x80u - lo) * 0x01010101u;         // b + 0x80 - lo: bit 7 iff b >= lo
-    const uint32_t gt = x7 + (0x7Fu - hi) * 0x01010101u;         // b + 0x7F - hi: bit 7 iff b > hi
-    return ge & ~gt;
-}
-TK_DEV uint32_t tkf_eq(uint32_t x7, uint32_t v) {                // bit 7 set iff b == v
-    const uint32_t y = x7 ^ (v * 0x01010101u);
-    return ~(y + 0x7F7F7F7Fu);
-}
-
+// 16 bytes per lane -> the 8 bit planes (already in lane layout: bit i of plane b = bit b of byte i) -> the class
+// masks as boolean functions of the planes.  ASCII classes of the pattern of src/tekkenizer.rs:123: L = [A-Za-z],
+// N = [0-9], S = \s (9..13, 0x20); bytes >= 0x80 only set HI.
 TK_DEV TkfClass tkf_classify(const uint32_t* x) {
-    // 4x4 byte transpose: y[j] = (byte j of x0, x1, x2, x3)
-    const uint32_t a0 = wv_perm(x[1], x[0], 0x05010400u), a1 = wv_perm(x[1], x[0], 0x07030602u);
-    const uint32_t a2 = wv_perm(x[3], x[2], 0x05010400u), a3 = wv_perm(x[3], x[2], 0x07030602u);
-    uint32_t y[4];
-    y[0] = wv_perm(a2, a0, 0x05040100u); y[1] = wv_perm(a2, a0, 0x07060302u);
-    y[2] = wv_perm(a3, a1, 0x05040100u); y[3] = wv_perm(a3, a1, 0x07060302u);
-    uint32_t fL[4], fN[4], fS[4], fNL[4], fSP[4], fAP[4], fHI[4], fSTMD[4], fRV[4], fE[4], fLL[4];
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t hi = y[j] & 0x80808080u, nhi = ~hi;
-        const uint32_t x7 = y[j] & 0x7F7F7F7Fu, f = x7 | 0x20202020u;
-        fHI[j] = hi;
-        fL[j] = tkf_range(f, 0x61u, 0x7Au) & nhi;
-        fN[j] = tkf_range(x7, 0x30u, 0x39u) & nhi;
-        fSP[j] = tkf_eq(x7, 0x20u) & nhi;
-        fS[j] = (tkf_range(x7, 9u, 13u) & nhi) | fSP[j];
-        fNL[j] = (tkf_eq(x7, 10u) | tkf_eq(x7, 13u)) & nhi;
-        fAP[j] = tkf_eq(x7, 0x27u) & nhi;
-        fSTMD[j] = (tkf_range(f, 0x73u, 0x74u) | tkf_eq(f, 0x6Du) | tkf_eq(f, 0x64u)) & nhi;
-        fRV[j] = (tkf_eq(f, 0x72u) | tkf_eq(f, 0x76u)) & nhi;
-        fE[j] = tkf_eq(f, 0x65u) & nhi;
-        fLL[j] = tkf_eq(f, 0x6Cu) & nhi;
-    }
+    uint32_t a_lo = x[0], a_hi = x[1], b_lo = x[2], b_hi = x[3];
+    tkf_transpose8(a_lo, a_hi);
+    tkf_transpose8(b_lo, b_hi);
+    const uint32_t p0 = wv_perm(b_lo, a_lo, 0x07030400u) & 0xFFFFu, p1 = wv_perm(b_lo, a_lo, 0x07030501u) & 0xFFFFu;
+    const uint32_t p2 = wv_perm(b_lo, a_lo, 0x07030602u) & 0xFFFFu, p3 = wv_perm(b_lo, a_lo, 0x07030703u) & 0xFFFFu;
+    const uint32_t p4 = wv_perm(b_hi, a_hi, 0x07030400u) & 0xFFFFu, p5 = wv_perm(b_hi, a_hi, 0x07030501u) & 0xFFFFu;
+    const uint32_t p6 = wv_perm(b_hi, a_hi, 0x07030602u) & 0xFFFFu, p7 = wv_perm(b_hi, a_hi, 0x07030703u) & 0xFFFFu;
     TkfClass c;
-    c.L = tkf_gather(fL[0], fL[1], fL[2], fL[3]);
-    c.N = tkf_gather(fN[0], fN[1], fN[2], fN[3]);
-    c.S = tkf_gather(fS[0], fS[1], fS[2], fS[3]);
-    c.NL = tkf_gather(fNL[0], fNL[1], fNL[2], fNL[3]);
-    c.SP = tkf_gather(fSP[0], fSP[1], fSP[2], fSP[3]);
-    c.AP = tkf_gather(fAP[0], fAP[1], fAP[2], fAP[3]);
-    c.HI = tkf_gather(fHI[0], fHI[1], fHI[2], fHI[3]);
-    c.STMD = tkf_gather(fSTMD[0], fSTMD[1], fSTMD[2], fSTMD[3]);
-    c.RV = tkf_gather(fRV[0], fRV[1], fRV[2], fRV[3]);
-    c.E = tkf_gather(fE[0], fE[1], fE[2], fE[3]);
-    c.LL = tkf_gather(fLL[0], fLL[1], fLL[2], fLL[3]);
+    const uint32_t hz = TKF_WM & ~(p7 | p6 | p5 | p4);            // high nibble 0
+    const uint32_t pre = p6 & ~p7;                                // 0x40..0x7F: letters differ in bit 5 only
+    c.HI = p7;
+    c.L = pre & (p4 | p3 | p2 | p1 | p0) & ~(p4 & p3 & (p2 | (p1 & p0)));       // low five bits in 1..26
+    c.N = p5 & p4 & ~(p7 | p6) & ~(p3 & (p2 | p1));                             // 0x30..0x39
+    c.SP = p5 & ~(p7 | p6 | p4) & ~(p3 | p2 | p1 | p0);                         // 0x20
+    c.S = (hz & p3 & ((~p2 & (p1 | p0)) | (p2 & ~p1))) | c.SP;                  // 9..13, 0x20
+    c.NL = hz & p3 & ((~p2 & p1 & ~p0) | (p2 & ~p1 & p0));                      // 10, 13
+    c.AP = p5 & ~(p7 | p6 | p4) & ~p3 & p2 & p1 & p0;                           // 0x27
+    const uint32_t q = pre & ~p3 & p4;                                          // low five bits 10xxx
+    c.STMD = (q & ((~p2 & p1 & p0) | (p2 & ~p1 & ~p0))) |                       // s 10011, t 10100
+             (pre & ~p4 & p2 & ~p1 & ((p3 & p0) | (~p3 & ~p0)));                // m 01101, d 00100
+    c.RV = q & p1 & ~p0;                                                        // r 10010, v 10110
+    c.E = pre & ~p4 & ~p3 & p2 & ~p1 & p0;                                      // e 00101
+    c.LL = pre & ~p4 & p3 & p2 & ~p1 & ~p0;                                     // l 01100
     return c;
 }
 
@@ -314,9 +299,14 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // ---- 5. enumerate the pieces: positions of the set bits of PS from the commit start on -------
     const uint32_t PSown = PS & commit_mask;
     const uint32_t PSlist = lane >= 2 ? PS : 0u;            // commit range and right halo (ends of the last pieces)
-    uint32_t np_all, np_own;
-    const uint32_t pfx_all = tkf_scan_excl((uint32_t)__builtin_popcount(PSlist), lane, &np_all);
-    const uint32_t pfx_own = tkf_scan_excl((uint32_t)__builtin_popcount(PSown), lane, &np_own);
+    uint32_t np_all, np_own, pfx_all, pfx_own;
+    {
+        // one scan for both counts (each < 2^16)
+        uint32_t tot;
+        const uint32_t pf = tkf_scan_excl((uint32_t)__builtin_popcount(PSlist) | ((uint32_t)__builtin_popcount(PSown) << 16), lane, &tot);
+        pfx_all = pf & 0xFFFFu; pfx_own = pf >> 16;
+        np_all = tot & 0xFFFFu; np_own = tot >> 16;
+    }
     {
         uint32_t w = PSlist, idx = pfx_all;
         while (wv_ballot(w != 0u)) {
@@ -337,7 +327,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
     uint32_t* tmp = a.tmp + c * TKF_STRIDE;
     uint32_t E = 0;                                         // slots beyond one per piece so far
-    uint32_t nmiss = 0;
+    uint32_t nmiss_a = 0, nmiss_b = 0;
     const uint32_t nbatch = (np_own + 63u) / 64u;
     for (uint32_t j = 0; j < nbatch; ++j) {
         const uint32_t idx = j * 64u + (uint32_t)lane;
@@ -389,12 +379,16 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             uint32_t tot;
             slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
             E += tot;
-            // queue the misses in the chunk's own region (no global atomics), records in piece order
+            // queue the misses in the chunk's own region (no global atomics), records in piece order: pieces of up to
+            // 8 bytes from the front, longer ones from the back (the merge kernel runs them in separate waves)
+            const uint64_t MBa = wv_ballot(miss && len <= 8u), MBb = MB & ~MBa;
             if (miss) {
-                const uint32_t mi = nmiss + (uint32_t)tk_popc64(MB & tk_lowmask(lane));
-                a.miss_list[c * TKF_MISSCAP + mi] = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
+                const uint32_t rec = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
+                if (len <= 8u) a.miss_list[c * TKF_MISSCAP + nmiss_a + (uint32_t)tk_popc64(MBa & tk_lowmask(lane))] = rec;
+                else a.miss_list[c * TKF_MISSCAP + (TKF_MISSCAP - 1u) - (nmiss_b + (uint32_t)tk_popc64(MBb & tk_lowmask(lane)))] = rec;
             }
-            nmiss += (uint32_t)tk_popc64(MB);
+            nmiss_a += (uint32_t)tk_popc64(MBa);
+            nmiss_b += (uint32_t)tk_popc64(MBb);
         }
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
@@ -404,7 +398,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     }
     if (lane == 0) {
         a.kcount[c] = np_own + E;
-        a.miss_count[c] = nmiss;
+        a.miss_count[c] = nmiss_a;
+        a.miss_count_b[c] = nmiss_b;
     }
 
     // ---- 7. per-document outputs: slot of every document start, fall-back flags ---------------------
@@ -465,18 +460,23 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 
 TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane);
 
-// 64 queued pieces per wave: item i of the global queue order lives in the queue of the chunk c with
-// miss_prefix[c] <= i < miss_prefix[c + 1] (exclusive prefix sums of miss_count, total at [n_chunks]).
+// 64 queued pieces per wave, all of one class (<= 8 bytes / longer): item i of a class lives in the queue of the
+// chunk c with prefix[c] <= i < prefix[c + 1] (exclusive prefix sums of the class's per-chunk counts, total at
+// [n_chunks]).  The waves of the short class come first.
 TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
-    const uint64_t total = a.miss_prefix[a.n_chunks];
-    const uint64_t item0 = wave_id * 64;
+    const uint64_t total_a = a.miss_prefix[a.n_chunks], total_b = a.miss_prefix_b[a.n_chunks];
+    const uint64_t waves_a = (total_a + 63) / 64;
+    const bool cls_b = wave_id >= waves_a;            // wave-uniform
+    const uint64_t* prefix = cls_b ? a.miss_prefix_b : a.miss_prefix;
+    const uint64_t total = cls_b ? total_b : total_a;
+    const uint64_t item0 = (cls_b ? wave_id - waves_a : wave_id) * 64;
     if (item0 >= total) return;                       // wave-uniform
     // chunk of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
     uint64_t lo = 0, hi = a.n_chunks;                 // invariant: prefix[lo] <= item0 < prefix[hi]
     while (hi - lo > 1) {
         const uint64_t step = (hi - lo + 63) / 64;
         const uint64_t q = lo + (uint64_t)lane * step;
-        const bool le = q < hi && a.miss_prefix[q] <= item0;
+        const bool le = q < hi && prefix[q] <= item0;
         const uint64_t LE = wv_ballot(le);            // a prefix of the lanes (lane 0 always)
         const int top = tk_msb64(LE);
         const uint64_t nlo = lo + (uint64_t)top * step;
@@ -489,17 +489,20 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
     const bool have = item < total;
     uint64_t cl = lo, ch = lo + 64 < a.n_chunks ? lo + 64 : a.n_chunks;   // prefix[cl] <= item < prefix[ch]
     if (have) {
-        while (a.miss_prefix[ch] <= item) {           // never past n_chunks: prefix[n_chunks] = total > item
+        while (prefix[ch] <= item) {                  // never past n_chunks: prefix[n_chunks] = total > item
             cl = ch;
             ch = ch + 64 < a.n_chunks ? ch + 64 : a.n_chunks;
         }
         while (ch - cl > 1) {
             const uint64_t mid = (cl + ch) / 2;
-            if (a.miss_prefix[mid] <= item) cl = mid; else ch = mid;
+            if (prefix[mid] <= item) cl = mid; else ch = mid;
         }
     }
     uint32_t rec = 0;
-    if (have) rec = a.miss_list[cl * TKF_MISSCAP + (item - a.miss_prefix[cl])];
+    if (have) {
+        const uint64_t k = item - prefix[cl];
+        rec = a.miss_list[cl * TKF_MISSCAP + (cls_b ? (uint64_t)(TKF_MISSCAP - 1u) - k : k)];
+    }
     tk_merge_items(a, have, rec, (uint32_t)cl, lane);
 }
 

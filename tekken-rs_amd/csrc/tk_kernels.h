@@ -36,7 +36,7 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
                                    uint32_t eos_id, int add_bos, int add_eos, hipStream_t s);
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss, hipStream_t s);  // n_miss = a.miss_prefix[n_chunks], read back by the host
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss_a, uint64_t n_miss_b, hipStream_t s);  // totals of the two prefix arrays, read back by the host
 
 // ---- decode path (tk_decode.hip) ----
 struct TkDecodeArgs {

@@ -243,6 +243,8 @@ __global__ void tk_wave_selftest_kernel(uint32_t* fail) {
     }
     if (wv_min_u32(0xFFFFFFFFu) != 0xFFFFFFFFu) bad |= 128u;
     if (wv_readlane(v, 17) != 1017u) bad |= 256u;
+    if (wv_scan_incl_u32((uint32_t)lane * 3u + 1u) != (uint32_t)(3 * (lane * (lane + 1)) / 2 + lane + 1)) bad |= 512u;
+    if (wv_perm(0x07060504u, 0x03020100u, 0x05010400u) != 0x05010400u || wv_inverse_ballot(0xF0F0F0F0F0F0F0F1ull) != ((lane & 4) != 0 || lane == 0)) bad |= 1024u;
     if (bad) atomicOr(fail, bad);
 }
 

@@ -84,4 +84,17 @@ TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) {
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
 }
 
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside the rows of 16, then the two row broadcasts
+// (lanes without a source read 0) -- VALU only, no LDS crossbar
+TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 #endif

@@ -215,4 +215,14 @@ TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 
 TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) { memcpy(x, p, 16); }
 
+TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {
+    tkemu::Wave* w = tkemu::g_wave;
+    const int lane = w->cur;
+    w->dep_u32[lane] = v;
+    tkemu::yield_op(tkemu::OP_SHFL);
+    uint32_t s = 0;
+    for (int l = 0; l <= lane; ++l) s += tkemu::g_wave->snap_u32[l];
+    return s;
+}
+
 #endif

@@ -108,3 +108,17 @@ def test_emu_flat_runs_and_misses(test_vocab):
     words = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(1, 30))) for _ in range(3000)]
     docs = [" ".join(rng.choice(words) for _ in range(rng.randint(1, 120))).encode() for _ in range(25)]
     assert _emu_check(test_vocab, docs) == []
+
+
+def test_emu_flat_every_ascii_byte_pair(small_vocab):
+    """classification by bit planes: every pair of ASCII byte values, at every lane offset (documents of 4 bytes
+    packed back to back, a 5-byte document now and then to shift the phase)."""
+    docs = []
+    for b1 in range(128):
+        for b2 in range(0, 128, 1 if b1 in (0x27, 0x20, 10, 13, 9, 0x30, 0x41, 0x61, 0x7F, 0) else 7):
+            docs.append(bytes([0x61, b1, b2, 0x31]))
+        docs.append(b"'re s")
+    _emu_check(small_vocab, docs, False, False)
+    # bytes >= 0x80 only hand the document back
+    flagged = _emu_check(small_vocab, [b"ab", bytes([0x61, 0xC3, 0xA9]), b"cd"], False, False)
+    assert flagged == [1]

@@ -59,6 +59,9 @@ struct tk_ctx {
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_mcnt_b, f_mpfx_b, f_holes, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
+    int pipeline_forced = 0;       // TK_PIPELINE: 0 adaptive, 1 flat, 2 per-document
+    bool probe_needed = true;      // sample the next batch before choosing the pipeline
+    bool last_was_doc = false;
     uint64_t n_flagged = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -150,7 +153,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         c->err = "wave primitive self-test failed on this device (mask " + std::to_string(bad) + ")";
         return fail(TK_ERR_RUNTIME);
     }
-    if (const char* pl = getenv("TK_PIPELINE")) c->use_flat = strcmp(pl, "doc") != 0;  // "doc": per-document kernels only
+    if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
+        c->pipeline_forced = strcmp(pl, "doc") == 0 ? 2 : strcmp(pl, "flat") == 0 ? 1 : 0;
     *out_ctx = c;
     return TK_OK;
 }
@@ -390,11 +394,37 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     return TK_OK;
 }
 
+// Pipeline choice.  The flat kernel is the fast path for ASCII text and hands every document with a byte >= 0x80 back
+// to the per-document kernels; a batch that is mostly non-ASCII is cheaper on the per-document kernels alone.  The
+// choice is adaptive: a 1024-block sample of the text decides (tk_ascii_probe_kernel) whenever the previous batch
+// gave a reason to look (first batch, per-document pipeline in use, or more than 10 % handed back).
 static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
-    if (c->use_flat) return run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
-    c->n_flagged = 0;
-    return run_pipeline_doc(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+    bool flat = c->pipeline_forced != 2;
+    if (c->pipeline_forced == 0 && c->probe_needed && n_bytes >= 65536) {
+        uint32_t hi_blocks = 0;
+        const uint32_t n_samples = 1024;
+        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 6, 0, 4, s));
+        TK_HIP(c, tk_launch_ascii_probe(d_bytes, n_bytes, n_samples, (uint32_t*)c->counters.p + 6, s));
+        TK_HIP(c, hipMemcpyAsync(&hi_blocks, (uint32_t*)c->counters.p + 6, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        flat = hi_blocks * 2 < n_samples;   // fewer than half of the sampled 1-KB blocks hold a non-ASCII byte
+        if (getenv("TK_DEBUG_LOG")) fprintf(stderr, "[tk] probe: %u of %u sampled blocks non-ASCII -> %s pipeline\n", hi_blocks, n_samples, flat ? "flat" : "per-document");
+    } else if (c->pipeline_forced == 0) {
+        flat = !c->last_was_doc;
+    }
+    c->use_flat = flat;
+    c->last_was_doc = !flat;
+    int rc;
+    if (flat) {
+        rc = run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+        c->probe_needed = c->n_flagged * 10 > n_docs;
+    } else {
+        c->n_flagged = 0;
+        rc = run_pipeline_doc(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+        c->probe_needed = true;
+    }
+    return rc;
 }
 
 extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,

@@ -1,5 +1,6 @@
 // tk_flat.hip -- gfx950 kernels of the flat (chunk-per-wave) tokenization path, see tk_flat_impl.h.
 //
+//   tk_ascii_probe_kernel     sample of the text: share of 1-KB blocks with a byte >= 0x80 (pipeline choice)
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
 //   tk_flat_kernel            split + lookup + merge of one 1024-byte region per wave, ids chunk-dense
 //   tk_merge_kernel           byte-pair merge of the queued pieces that missed the vocabulary, one lane per piece
@@ -31,6 +32,21 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     if (n_chunks == 0) return;
     if (c_hi > n_chunks - 1) c_hi = n_chunks - 1;
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
+}
+
+// Which pipeline suits this batch?  Every wave looks at one 1-KB block of the text (evenly spaced sample) and reports
+// whether it holds a byte >= 0x80; the host sends mostly non-ASCII batches straight to the per-document kernels.
+__global__ __launch_bounds__(TKF_BLOCK) void tk_ascii_probe_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
+                                                                    uint64_t n_samples, uint32_t* __restrict__ out) {
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
+    if (wave >= n_samples) return;
+    const uint64_t n_blocks = n_bytes / 1024;
+    const uint64_t blk = n_blocks ? (wave * n_blocks) / n_samples : 0;
+    const uint64_t p = blk * 1024 + (uint64_t)(threadIdx.x & 63) * 16;
+    bool hi = false;
+    for (int k = 0; k < 16; ++k)
+        if (p + k < n_bytes) hi |= bytes[p + k] >= 0x80u;
+    if (__ballot(hi) && (threadIdx.x & 63) == 0) atomicAdd(out, 1u);
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
@@ -243,6 +259,13 @@ hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, ui
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_flat_firstdoc_kernel, dim3(tkf_blocks(n_docs ? n_docs : 1)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs,
                        n_chunks, first_doc);
+    return hipGetLastError();
+}
+
+hipError_t tk_launch_ascii_probe(const uint8_t* bytes, uint64_t n_bytes, uint32_t n_samples, uint32_t* d_count, hipStream_t s) {
+    if (n_bytes == 0 || n_samples == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_ascii_probe_kernel, dim3((n_samples + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64)), dim3(TKF_BLOCK), 0, s,
+                       bytes, n_bytes, (uint64_t)n_samples, d_count);
     return hipGetLastError();
 }
 

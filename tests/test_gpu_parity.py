@@ -107,6 +107,7 @@ def test_both_pipelines(tk, test_vocab, monkeypatch):
     orc = helpers.oracle_for(test_vocab)
     docs = helpers.mixed_docs(120, 40, 200, max_len=40000) + helpers.random_unicode_docs(300)
     exp = [orc.encode(d, True, True) for d in docs]
+    monkeypatch.setenv("TK_PIPELINE", "flat")
     flat = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
     assert flat.encode_docs(docs, True, True) == exp
     st = flat.last_stats()
@@ -117,6 +118,18 @@ def test_both_pipelines(tk, test_vocab, monkeypatch):
     assert per_doc.encode_docs(docs, True, True) == exp
     assert per_doc.last_stats()["handed_back"] == 0
     per_doc.close()
+    # adaptive (default): a mostly non-ASCII batch goes straight to the per-document kernels, an ASCII batch to the flat one
+    monkeypatch.delenv("TK_PIPELINE")
+    auto = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    d, o = corpus.generate("mixed", 200, 2048, seed=corpus.BASE_SEED + 2)
+    mixed = corpus.docs_of(d, o)
+    assert auto.encode_docs(mixed, True, True) == [orc.encode(x, True, True) for x in mixed]
+    assert auto.last_stats()["handed_back"] == 0
+    d, o = corpus.generate("ascii", 400, 512, seed=corpus.BASE_SEED + 1)
+    asc = corpus.docs_of(d, o) + mixed[:3]
+    assert auto.encode_docs(asc, True, True) == [orc.encode(x, True, True) for x in asc]
+    assert auto.last_stats()["handed_back"] == 3
+    auto.close()
 
 
 def test_flat_path_stress(eng_small, test_vocab):

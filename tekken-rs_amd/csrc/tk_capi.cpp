@@ -57,11 +57,9 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
-    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_mcnt_b, f_mpfx_b, f_holes, f_info;  // flat path (tk_flat.hip)
+    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_holes, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
-    int pipeline_forced = 0;       // TK_PIPELINE: 0 adaptive, 1 flat, 2 per-document
-    bool probe_needed = true;      // sample the next batch before choosing the pipeline
-    bool last_was_doc = false;
+    int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -167,7 +165,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
-                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_mcnt_b, &c->f_mpfx_b, &c->f_holes, &c->f_info};
+                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_holes, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -290,15 +288,13 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, c->f_flags.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->f_todo.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->f_miss.reserve((n_chunks * TKF_MISSCAP + 64) * 4));  // worst case; only the used records are ever touched
-    TK_HIP(c, c->f_mcnt.reserve((n_chunks + 1) * 4));
-    TK_HIP(c, c->f_mpfx.reserve((n_chunks + 2) * 8));
-    TK_HIP(c, c->f_mcnt_b.reserve((n_chunks + 1) * 4));
-    TK_HIP(c, c->f_mpfx_b.reserve((n_chunks + 2) * 8));
+    TK_HIP(c, c->f_mcnt.reserve((4 * n_chunks + 1) * 4));
+    TK_HIP(c, c->f_mpfx.reserve((4 * n_chunks + 2) * 8));
     TK_HIP(c, c->f_holes.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->f_info.reserve((n_docs + 1) * 16));
     TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
-    const uint64_t scan_n = n_docs > n_chunks ? n_docs : n_chunks;
+    const uint64_t scan_n = n_docs > 4 * n_chunks ? n_docs : 4 * n_chunks;
     TK_HIP(c, c->block_sums.reserve((scan_n / 2048 + 4) * 8));
 
     TkFlatArgs fa;
@@ -316,8 +312,6 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.miss_list = (uint32_t*)c->f_miss.p;
     fa.miss_count = (uint32_t*)c->f_mcnt.p;
     fa.miss_prefix = (const uint64_t*)c->f_mpfx.p;
-    fa.miss_count_b = (uint32_t*)c->f_mcnt_b.p;
-    fa.miss_prefix_b = (const uint64_t*)c->f_mpfx_b.p;
     fa.holes = (uint32_t*)c->f_holes.p;
     fa.t = c->dview;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
@@ -331,16 +325,15 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, tk_launch_flat(fa, s));
     TK_HIP(c, hipEventRecord(c->ev[1], s));
     TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
-    TK_HIP(c, tk_launch_scan(fa.miss_count, n_chunks, (uint64_t*)c->f_mpfx.p, (uint64_t*)c->block_sums.p, s));
-    TK_HIP(c, tk_launch_scan(fa.miss_count_b, n_chunks, (uint64_t*)c->f_mpfx_b.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_scan(fa.miss_count, 4 * n_chunks, (uint64_t*)c->f_mpfx.p, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_scan(fa.kcount, n_chunks, (uint64_t*)c->f_P.p, (uint64_t*)c->block_sums.p, s));
     uint32_t n_todo = 0;
-    uint64_t n_miss_a = 0, n_miss_b = 0;
+    uint64_t n_narrow = 0, n_all = 0;   // queued pieces of 2..16 bytes / of all classes
     TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(&n_miss_a, (uint64_t*)c->f_mpfx.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(&n_miss_b, (uint64_t*)c->f_mpfx_b.p + n_chunks, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&n_narrow, (uint64_t*)c->f_mpfx.p + 2 * n_chunks, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipMemcpyAsync(&n_all, (uint64_t*)c->f_mpfx.p + 4 * n_chunks, 8, hipMemcpyDeviceToHost, s));
     TK_HIP(c, hipStreamSynchronize(s));
-    TK_HIP(c, tk_launch_merge(fa, n_miss_a, n_miss_b, s));
+    TK_HIP(c, tk_launch_merge(fa, n_narrow, n_all - n_narrow, s));
     c->n_flagged = n_todo;
     c->n_long_docs = 0;
     if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,
@@ -394,37 +387,13 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     return TK_OK;
 }
 
-// Pipeline choice.  The flat kernel is the fast path for ASCII text and hands every document with a byte >= 0x80 back
-// to the per-document kernels; a batch that is mostly non-ASCII is cheaper on the per-document kernels alone.  The
-// choice is adaptive: a 1024-block sample of the text decides (tk_ascii_probe_kernel) whenever the previous batch
-// gave a reason to look (first batch, per-document pipeline in use, or more than 10 % handed back).
+// Pipeline choice: the flat pipeline, unless TK_PIPELINE=doc asks for the per-document kernels alone (tests / A-B runs).
 static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
-    bool flat = c->pipeline_forced != 2;
-    if (c->pipeline_forced == 0 && c->probe_needed && n_bytes >= 65536) {
-        uint32_t hi_blocks = 0;
-        const uint32_t n_samples = 1024;
-        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 6, 0, 4, s));
-        TK_HIP(c, tk_launch_ascii_probe(d_bytes, n_bytes, n_samples, (uint32_t*)c->counters.p + 6, s));
-        TK_HIP(c, hipMemcpyAsync(&hi_blocks, (uint32_t*)c->counters.p + 6, 4, hipMemcpyDeviceToHost, s));
-        TK_HIP(c, hipStreamSynchronize(s));
-        flat = hi_blocks * 2 < n_samples;   // fewer than half of the sampled 1-KB blocks hold a non-ASCII byte
-        if (getenv("TK_DEBUG_LOG")) fprintf(stderr, "[tk] probe: %u of %u sampled blocks non-ASCII -> %s pipeline\n", hi_blocks, n_samples, flat ? "flat" : "per-document");
-    } else if (c->pipeline_forced == 0) {
-        flat = !c->last_was_doc;
-    }
-    c->use_flat = flat;
-    c->last_was_doc = !flat;
-    int rc;
-    if (flat) {
-        rc = run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
-        c->probe_needed = c->n_flagged * 10 > n_docs;
-    } else {
-        c->n_flagged = 0;
-        rc = run_pipeline_doc(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
-        c->probe_needed = true;
-    }
-    return rc;
+    c->use_flat = c->pipeline_forced != 2;
+    if (c->use_flat) return run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+    c->n_flagged = 0;
+    return run_pipeline_doc(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
 }
 
 extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,

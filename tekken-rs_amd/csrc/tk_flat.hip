@@ -1,9 +1,9 @@
 // tk_flat.hip -- gfx950 kernels of the flat (chunk-per-wave) tokenization path, see tk_flat_impl.h.
 //
-//   tk_ascii_probe_kernel     sample of the text: share of 1-KB blocks with a byte >= 0x80 (pipeline choice)
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
 //   tk_flat_kernel            split + lookup + merge of one 1024-byte region per wave, ids chunk-dense
-//   tk_merge_kernel           byte-pair merge of the queued pieces that missed the vocabulary, one lane per piece
+//   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
+//   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32-wide register arrays / one lane per byte)
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel
 //   tk_flat_counts_kernel     ids per document from the chunk prefix sums and the document-start ranks
 //   tk_flat_assemble_kernel   chunk-dense ids -> packed ids in document order with BOS / EOS
@@ -34,21 +34,6 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
 }
 
-// Which pipeline suits this batch?  Every wave looks at one 1-KB block of the text (evenly spaced sample) and reports
-// whether it holds a byte >= 0x80; the host sends mostly non-ASCII batches straight to the per-document kernels.
-__global__ __launch_bounds__(TKF_BLOCK) void tk_ascii_probe_kernel(const uint8_t* __restrict__ bytes, uint64_t n_bytes,
-                                                                    uint64_t n_samples, uint32_t* __restrict__ out) {
-    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    if (wave >= n_samples) return;
-    const uint64_t n_blocks = n_bytes / 1024;
-    const uint64_t blk = n_blocks ? (wave * n_blocks) / n_samples : 0;
-    const uint64_t p = blk * 1024 + (uint64_t)(threadIdx.x & 63) * 16;
-    bool hi = false;
-    for (int k = 0; k < 16; ++k)
-        if (p + k < n_bytes) hi |= bytes[p + k] >= 0x80u;
-    if (__ballot(hi) && (threadIdx.x & 63) == 0) atomicAdd(out, 1u);
-}
-
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
     const int lane = wv_lane();
@@ -60,9 +45,14 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
     for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
-__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {
+__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    tk_merge_wave(a, wave, wv_lane());
+    tk_merge_wave<false>(a, wave, wv_lane());
+}
+
+__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
+    tk_merge_wave<true>(a, wave, wv_lane());
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
@@ -262,13 +252,6 @@ hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, ui
     return hipGetLastError();
 }
 
-hipError_t tk_launch_ascii_probe(const uint8_t* bytes, uint64_t n_bytes, uint32_t n_samples, uint32_t* d_count, hipStream_t s) {
-    if (n_bytes == 0 || n_samples == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_ascii_probe_kernel, dim3((n_samples + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64)), dim3(TKF_BLOCK), 0, s,
-                       bytes, n_bytes, (uint64_t)n_samples, d_count);
-    return hipGetLastError();
-}
-
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     uint64_t blocks = (a.n_chunks + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
@@ -278,10 +261,10 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss_a, uint64_t n_miss_b, hipStream_t s) {
-    const uint64_t waves = (n_miss_a + 63) / 64 + (n_miss_b + 63) / 64;   // one class per wave, the short class first
-    if (waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((waves + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_narrow, uint64_t n_wide, hipStream_t s) {
+    const uint64_t w1 = (n_narrow + 63) / 64, w2 = (n_wide + 63) / 64;
+    if (w1) hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((w1 + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
+    if (w2) hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)((w2 + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -10,7 +10,12 @@
 #define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
 #define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* 928 bytes committed per chunk */
 #define TKF_STRIDE (TKF_COMMIT + 64)                 /* id slots per chunk: a piece may reach 63 bytes past the commit range */
-#define TKF_MISSCAP (TKF_COMMIT / 2)                  /* queue records per chunk: a queued piece has >= 2 bytes */
+/* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): a chunk commits 928 bytes */
+#define TKF_MISSOFF0 0u
+#define TKF_MISSOFF1 464u                            /* 928 / 2 */
+#define TKF_MISSOFF2 568u                            /* + ceil(928 / 9) */
+#define TKF_MISSOFF3 624u                            /* + ceil(928 / 17) */
+#define TKF_MISSCAP 656u                             /* + ceil(928 / 33), rounded up */
 #define TKF_HOLE 0xFFFFFFFFu                         /* id slot reserved by a missed piece and not used */
 
 struct TkFlatArgs {
@@ -21,12 +26,10 @@ struct TkFlatArgs {
     uint32_t* tmp;               // [n_chunks * TKF_STRIDE] chunk-dense ids
     uint32_t* kcount;            // [n_chunks] id slots of the chunk (holes included)
     uint32_t* lstart;            // [n_docs] id slots of the chunk before the document's first byte
-    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17;
-                                 // pieces of <= 8 bytes from the front of the chunk's region, longer ones from its back
-    uint32_t* miss_count;        // [n_chunks] queued pieces of <= 8 bytes
-    uint32_t* miss_count_b;      // [n_chunks] queued pieces of > 8 bytes
-    const uint64_t* miss_prefix; // [n_chunks + 1] exclusive prefix sums of miss_count (the merge kernel's item order, short class)
-    const uint64_t* miss_prefix_b;  // same for miss_count_b
+    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17,
+                                 // sub-queue of length class k at TKF_MISSOFFk
+    uint32_t* miss_count;        // [4 * n_chunks] class-major: queued pieces of class k of chunk c at [k * n_chunks + c]
+    const uint64_t* miss_prefix; // [4 * n_chunks + 1] exclusive prefix sums of miss_count (the merge kernels' item order)
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags

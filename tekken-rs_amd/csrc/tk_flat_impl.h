@@ -19,10 +19,11 @@
 //     cut the stream into documents and squeeze the holes out.
 //
 // Regions overlap: 32 bytes of left halo (look-behind context), 64 of right halo (look-ahead, piece
-// ends), 928 committed.  The fast path is ASCII; a document with a byte >= 0x80, with a digit / CR-LF
-// run that covers the whole left halo, a white-space run that reaches the end of the region or a piece
-// of more than 64 bytes is flagged and redone by the per-document kernel (tk_encode_impl.h), which
-// handles everything.
+// ends), 928 committed.  ASCII is classified from the bit planes alone; a region with multi-byte code
+// points additionally looks the class of every lead byte up in the trie (the char-level rules use the
+// char-start mask).  A document with a digit / CR-LF run that covers the whole left halo, a white-space
+// run that reaches the end of the region or a piece of more than 64 bytes is flagged and redone by the
+// per-document kernel (tk_encode_impl.h), which handles everything.
 //
 // The rules are modelled in tools/flat_split_model.py (Python ints as masks, checked against the
 // oracle); this file is that model in lane layout.  Runs on the CPU wave emulator (tests/emu).
@@ -43,7 +44,8 @@
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
 #define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
-#define TKF_LDS_WORDS (TKF_L_BPFX + 64)
+#define TKF_L_CL (TKF_L_BPFX + 64)                  /* [3 * 64] classes L, N, S of the multi-byte code points */
+#define TKF_LDS_WORDS (TKF_L_CL + 3 * 64)
 
 
 // ------------------------------------------------------------------------------------------
@@ -69,17 +71,21 @@ TK_DEV uint32_t tkf_shr_any(uint32_t x, int k, int lane) {
 }
 TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
 
-// bits of `run` covered by a carry that starts at `seeds` (subset of run) and ripples upwards through
-// consecutive run bits, across lanes: per-lane add + 64-bit carry look-ahead over the lane carries
-TK_DEV uint32_t tkf_ripple(uint32_t run, uint32_t seeds) {
-    const uint32_t t = run + seeds;
+// a + b over the whole 1024-bit region: per-lane add, then a 64-bit carry look-ahead over the lane carries
+// (G = lanes that generate a carry, P = lanes that would pass one on) hands every lane its carry-in
+TK_DEV uint32_t tkf_add(uint32_t a, uint32_t b) {
+    const uint32_t t = a + b;
     const uint64_t G = wv_ballot((t >> TKF_W) != 0u);
-    const uint64_t P = wv_ballot(run == TKF_WM);
+    const uint64_t P = wv_ballot(t == TKF_WM);
     const uint64_t x = G | P;
     const uint64_t cin = (x + G) ^ x ^ G;  // carry into lane l = bit l
-    const uint32_t r = (t + (wv_inverse_ballot(cin) ? 1u : 0u)) & TKF_WM;
-    return (r ^ run) & run;
+    return (t + (wv_inverse_ballot(cin) ? 1u : 0u)) & TKF_WM;
 }
+// bits of `run` covered by a carry that starts at `seeds` (subset of run) and ripples upwards through
+// consecutive run bits, across lanes
+TK_DEV uint32_t tkf_ripple(uint32_t run, uint32_t seeds) { return (tkf_add(run, seeds) ^ run) & run; }
+// where a carry started at `seeds` comes to rest: the first position at or above each seed that is not in `run`
+TK_DEV uint32_t tkf_land(uint32_t run, uint32_t seeds) { return tkf_add(run, seeds) & ~run & TKF_WM; }
 
 TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
     (void)lane;
@@ -93,6 +99,8 @@ TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
 // ------------------------------------------------------------------------------------------
 struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
+    uint32_t U8C, LEAD, C5, BF;  // UTF-8: continuation bytes, lead bytes; C5 BF = U+017F (folds to 's')
+    bool nmb;                 // wave-uniform: the region holds a multi-byte \p{N} char
 };
 
 // 8x8 bit-matrix transpose of 8 bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte b holds bit b of every
@@ -136,6 +144,11 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     c.RV = q & p1 & ~p0;                                                        // r 10010, v 10110
     c.E = pre & ~p4 & ~p3 & p2 & ~p1 & p0;                                      // e 00101
     c.LL = pre & ~p4 & p3 & p2 & ~p1 & ~p0;                                     // l 01100
+    c.U8C = p7 & ~p6;
+    c.LEAD = p7 & p6;
+    c.C5 = p7 & p6 & ~(p5 | p4 | p3) & p2 & ~p1 & p0;                           // 1100 0101
+    c.BF = p7 & ~p6 & p5 & p4 & p3 & p2 & p1 & p0;                              // 1011 1111
+    c.nmb = false;
     return c;
 }
 
@@ -150,23 +163,36 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
 #define P1(x) (tkf_shl((x), 1) & nDS)
 #define N1(x) (tkf_shr((x), 1) & nDE)
     const uint32_t mL = m.L, mN = m.N, mS = m.S, NL = m.NL, SP = m.SP;
+    const uint32_t U8C = m.U8C, CS = TKF_WM & ~U8C;  // first byte of every code point
+    const bool u8 = tkf_any(m.HI);                   // wave-uniform: the region holds multi-byte code points
     const uint32_t mO = TKF_WM & ~(mL | mN | mS);
     const uint32_t pOS = P1(mO | SP);            // previous byte is class O or U+0020
     uint32_t CEND = 0;
     if (tkf_any(m.AP)) {                         // alt 1: fires only where a match starts at the apostrophe
         const uint32_t ok = m.AP & ~pOS;
         const uint32_t c2 = ok & N1(m.STMD);
-        const uint32_t c3 = ok & ~c2 & N1((m.RV & N1(m.E)) | (m.LL & N1(m.LL)));
+        uint32_t three = (m.RV & N1(m.E)) | (m.LL & N1(m.LL));
+        if (u8) three |= m.C5 & N1(m.BF);        // U+017F folds to 's' ((?i) of the pattern)
+        const uint32_t c3 = ok & ~c2 & N1(three);
         CEND = tkf_shl(c2, 2) | tkf_shl(c3, 3);
     }
     const uint32_t L1 = P1(mL), O1 = P1(mO);
     const uint32_t Lst = mL & ~L1;
-    const uint32_t psL = (mL & L1 & CEND) | (Lst & P1(mN | NL)) | (Lst & O1 & P1(pOS));
+    // "the O char before me is not available as alt 2's prefix": it is itself preceded by O or U+0020.
+    // X = such O chars, on all their bytes
+    uint32_t X = CS & mO & pOS;
+    if (u8) {
+        X |= P1(X) & U8C;
+        X |= P1(X) & U8C;
+        X |= P1(X) & U8C;
+    }
+    const uint32_t psL = (mL & L1 & CEND) | (Lst & P1(mN | NL)) | (Lst & P1(X));
     const uint32_t psO = mO & ~O1 & ~P1(SP);
-    // numbers: every 3rd char of a run (\p{N}{1,3}), prefix doubling
+    // numbers: every 3rd char of a run (\p{N}{1,3})
     const uint32_t N1m = P1(mN);
     uint32_t psN = mN & ~N1m;
-    {
+    if (!m.nmb) {
+        // one byte per char: prefix doubling on byte positions
         const uint32_t N2m = P1(N1m);
         uint32_t M = mN & N1m & N2m & P1(N2m);
         int k = 3;
@@ -174,6 +200,15 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
             psN |= tkf_shl_any(psN, k, lane) & M;
             M &= tkf_shl_any(M, k, lane);
             k *= 2;
+        }
+    } else {
+        // multi-byte digits: walk the runs three CHARS at a time (next char start = where a carry through the
+        // continuation bytes comes to rest)
+        uint32_t cur = psN;
+        while (tkf_any(cur)) {
+            for (int q = 0; q < 3; ++q) cur = tkf_land(U8C, tkf_shl(cur, 1)) & mN & nDS;
+            cur &= ~psN;
+            psN |= cur;
         }
     }
     // white space
@@ -192,7 +227,14 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
             k *= 2;
         }
     }
-    const uint32_t psS = (SPR & ~cont) | (tkf_shl(Z, 1) & cont & ~Z) | (SPR & ~tkf_shr(cont, 1) & ~Z & nDE);
+    uint32_t last = SPR & ~tkf_shr(cont, 1) & ~Z & nDE;   // last byte of a run that a non-space char follows
+    if (u8) {                                              // -> the first byte of its char
+        last = (last & CS) | N1(last & U8C);
+        last = (last & CS) | N1(last & U8C);
+        last = (last & CS) | N1(last & U8C);
+        last &= CS;
+    }
+    const uint32_t psS = (SPR & ~cont) | (tkf_shl(Z, 1) & cont & ~Z) | last;
 #undef P1
 #undef N1
     *SPR_out = SPR;
@@ -227,7 +269,52 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
     }
-    const TkfClass m = tkf_classify(x);
+    TkfClass m = tkf_classify(x);
+    if (tkf_any(m.HI)) {
+        // multi-byte code points: every lane walks the lead bytes among its 16 bytes, decodes the code point, looks its
+        // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
+        uint32_t* cl = lds + TKF_L_CL;
+        cl[lane] = 0u; cl[64 + lane] = 0u; cl[128 + lane] = 0u;
+        wv_lds_sync();
+        bool nmb = false;
+        uint32_t w = m.LEAD;
+        const int64_t g = r0 + 16 * lane;
+        while (wv_ballot(w != 0u)) {
+            if (w) {
+                const int i = __builtin_ctz(w);
+                w &= w - 1u;
+                const int64_t q = g + i;         // a lead byte is a real byte: 0 <= q < n
+                const uint32_t b0 = a.bytes[q];
+                const uint32_t b1 = q + 1 < n ? (uint32_t)a.bytes[q + 1] : 0u;
+                const uint32_t b2 = q + 2 < n ? (uint32_t)a.bytes[q + 2] : 0u;
+                const uint32_t b3 = q + 3 < n ? (uint32_t)a.bytes[q + 3] : 0u;
+                uint32_t cp = 0xFFFFFFFFu, clen = 1;
+                if (b0 < 0xE0u) {
+                    if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
+                } else if (b0 < 0xF0u) {
+                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
+                        cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
+                    }
+                } else if (b0 < 0xF8u) {
+                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
+                        cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
+                    }
+                }
+                const uint32_t cls = cp != 0xFFFFFFFFu ? tk_uc_class(t, cp) : TK_CLS_O;
+                if (cls != TK_CLS_O) {
+                    const uint32_t bits = ((1u << clen) - 1u) << i;   // up to bit 18
+                    wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, bits & TKF_WM);
+                    if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, bits >> TKF_W);
+                    if (cls == TK_CLS_N) nmb = true;
+                }
+            }
+        }
+        wv_lds_sync();
+        m.L |= cl[lane];
+        m.N |= cl[64 + lane];
+        m.S |= cl[128 + lane];
+        m.nmb = wv_ballot(nmb) != 0ull;
+    }
     if (a.dbg_ablate & 16) {
         if (lane == 0) a.kcount[c] = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
         return;
@@ -269,11 +356,12 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     }
 
     // ---- 4. positions that make their document fall back ---------------------------------------
-    uint32_t BAD = m.HI & commit_mask;
+    uint32_t BAD = 0;
     {
         // (A) a digit / CR-LF run that comes from below the region and covers the whole left halo
         const uint32_t d0 = wv_readlane(DS, 0), d1 = wv_readlane(DS, 1);
-        const uint32_t n0 = wv_readlane(m.N, 0), n1 = wv_readlane(m.N, 1);
+        // (the region may begin inside a code point: its leading continuation bytes have no class and count as part of the run)
+        const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0), n1 = wv_readlane(m.N, 1);
         const uint32_t l0 = wv_readlane(m.NL, 0), l1 = wv_readlane(m.NL, 1);
         const bool covered = (n0 == TKF_WM && n1 == TKF_WM) || (l0 == TKF_WM && l1 == TKF_WM);
         if (r0 > 0 && d0 == 0u && d1 == 0u && covered && lane == 2) BAD |= 1u;
@@ -327,7 +415,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
     uint32_t* tmp = a.tmp + c * TKF_STRIDE;
     uint32_t E = 0;                                         // slots beyond one per piece so far
-    uint32_t nmiss_a = 0, nmiss_b = 0;
+    uint32_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;
     const uint32_t nbatch = (np_own + 63u) / 64u;
     for (uint32_t j = 0; j < nbatch; ++j) {
         const uint32_t idx = j * 64u + (uint32_t)lane;
@@ -379,16 +467,22 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             uint32_t tot;
             slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
             E += tot;
-            // queue the misses in the chunk's own region (no global atomics), records in piece order: pieces of up to
-            // 8 bytes from the front, longer ones from the back (the merge kernel runs them in separate waves)
-            const uint64_t MBa = wv_ballot(miss && len <= 8u), MBb = MB & ~MBa;
+            // queue the misses in the chunk's own region (no global atomics), records in piece order, one sub-queue per
+            // length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one class per wave
+            const uint32_t cls = len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : 3u;
+            const uint64_t M0 = wv_ballot(miss && cls == 0u), M1 = wv_ballot(miss && cls == 1u);
+            const uint64_t M2 = wv_ballot(miss && cls == 2u), M3 = MB & ~(M0 | M1 | M2);
             if (miss) {
-                const uint32_t rec = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
-                if (len <= 8u) a.miss_list[c * TKF_MISSCAP + nmiss_a + (uint32_t)tk_popc64(MBa & tk_lowmask(lane))] = rec;
-                else a.miss_list[c * TKF_MISSCAP + (TKF_MISSCAP - 1u) - (nmiss_b + (uint32_t)tk_popc64(MBb & tk_lowmask(lane)))] = rec;
+                const uint64_t Mk = cls == 0u ? M0 : cls == 1u ? M1 : cls == 2u ? M2 : M3;
+                const uint32_t nk = cls == 0u ? nm0 : cls == 1u ? nm1 : cls == 2u ? nm2 : nm3;
+                const uint32_t off = cls == 0u ? TKF_MISSOFF0 : cls == 1u ? TKF_MISSOFF1 : cls == 2u ? TKF_MISSOFF2 : TKF_MISSOFF3;
+                a.miss_list[c * TKF_MISSCAP + off + nk + (uint32_t)tk_popc64(Mk & tk_lowmask(lane))] =
+                    pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
             }
-            nmiss_a += (uint32_t)tk_popc64(MBa);
-            nmiss_b += (uint32_t)tk_popc64(MBb);
+            nm0 += (uint32_t)tk_popc64(M0);
+            nm1 += (uint32_t)tk_popc64(M1);
+            nm2 += (uint32_t)tk_popc64(M2);
+            nm3 += (uint32_t)tk_popc64(M3);
         }
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
@@ -398,8 +492,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     }
     if (lane == 0) {
         a.kcount[c] = np_own + E;
-        a.miss_count[c] = nmiss_a;
-        a.miss_count_b[c] = nmiss_b;
+        a.miss_count[c] = nm0;                       // class-major: class k of chunk c at [k * n_chunks + c]
+        a.miss_count[a.n_chunks + c] = nm1;
+        a.miss_count[2 * a.n_chunks + c] = nm2;
+        a.miss_count[3 * a.n_chunks + c] = nm3;
     }
 
     // ---- 7. per-document outputs: slot of every document start, fall-back flags ---------------------
@@ -458,21 +554,22 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 // ------------------------------------------------------------------------------------------
 #define TKM_SHORT 16
 
+template <bool WIDE>
 TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane);
 
-// 64 queued pieces per wave, all of one class (<= 8 bytes / longer): item i of a class lives in the queue of the
-// chunk c with prefix[c] <= i < prefix[c + 1] (exclusive prefix sums of the class's per-chunk counts, total at
-// [n_chunks]).  The waves of the short class come first.
+// 64 queued pieces per wave.  The queue counts are laid out class-major ([k * n_chunks + c]); their exclusive prefix
+// sums (total at [4 n_chunks]) order all queued pieces by class first, chunk second: item i lives in the sub-queue e
+// with prefix[e] <= i < prefix[e + 1].  WIDE = false takes the items of the classes 2..8 / 9..16 bytes, WIDE = true
+// those of 17..32 / 33..64 bytes (own kernel: its 32-wide register arrays would cost the common case occupancy).
+template <bool WIDE>
 TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
-    const uint64_t total_a = a.miss_prefix[a.n_chunks], total_b = a.miss_prefix_b[a.n_chunks];
-    const uint64_t waves_a = (total_a + 63) / 64;
-    const bool cls_b = wave_id >= waves_a;            // wave-uniform
-    const uint64_t* prefix = cls_b ? a.miss_prefix_b : a.miss_prefix;
-    const uint64_t total = cls_b ? total_b : total_a;
-    const uint64_t item0 = (cls_b ? wave_id - waves_a : wave_id) * 64;
+    const uint64_t* prefix = a.miss_prefix;
+    const uint64_t n_e = 4 * a.n_chunks;
+    const uint64_t first = WIDE ? prefix[2 * a.n_chunks] : 0, total = WIDE ? prefix[n_e] : prefix[2 * a.n_chunks];
+    const uint64_t item0 = first + wave_id * 64;
     if (item0 >= total) return;                       // wave-uniform
-    // chunk of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
-    uint64_t lo = 0, hi = a.n_chunks;                 // invariant: prefix[lo] <= item0 < prefix[hi]
+    // sub-queue of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
+    uint64_t lo = 0, hi = n_e;                        // invariant: prefix[lo] <= item0 < prefix[hi]
     while (hi - lo > 1) {
         const uint64_t step = (hi - lo + 63) / 64;
         const uint64_t q = lo + (uint64_t)lane * step;
@@ -484,14 +581,14 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
         lo = nlo;
         hi = nhi;
     }
-    // every lane: the chunk of its own item, searched from the wave's first chunk on
+    // every lane: the sub-queue of its own item, searched from the wave's first one on
     const uint64_t item = item0 + (uint64_t)lane;
     const bool have = item < total;
-    uint64_t cl = lo, ch = lo + 64 < a.n_chunks ? lo + 64 : a.n_chunks;   // prefix[cl] <= item < prefix[ch]
+    uint64_t cl = lo, ch = lo + 64 < n_e ? lo + 64 : n_e;   // prefix[cl] <= item < prefix[ch]
     if (have) {
-        while (prefix[ch] <= item) {                  // never past n_chunks: prefix[n_chunks] = total > item
+        while (prefix[ch] <= item) {                  // never past n_e: prefix[n_e] >= total > item
             cl = ch;
-            ch = ch + 64 < a.n_chunks ? ch + 64 : a.n_chunks;
+            ch = ch + 64 < n_e ? ch + 64 : n_e;
         }
         while (ch - cl > 1) {
             const uint64_t mid = (cl + ch) / 2;
@@ -499,11 +596,14 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
         }
     }
     uint32_t rec = 0;
+    uint64_t chunk = 0;
     if (have) {
-        const uint64_t k = item - prefix[cl];
-        rec = a.miss_list[cl * TKF_MISSCAP + (cls_b ? (uint64_t)(TKF_MISSCAP - 1u) - k : k)];
+        const uint64_t k = cl / a.n_chunks;
+        chunk = cl - k * a.n_chunks;
+        const uint32_t off = k == 0 ? TKF_MISSOFF0 : k == 1 ? TKF_MISSOFF1 : k == 2 ? TKF_MISSOFF2 : TKF_MISSOFF3;
+        rec = a.miss_list[chunk * TKF_MISSCAP + off + (item - prefix[cl])];
     }
-    tk_merge_items(a, have, rec, (uint32_t)cl, lane);
+    tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane);
 }
 
 // sequential merge of one piece per lane, parts in registers: N-wide arrays, every loop unrolled so that they are
@@ -565,6 +665,7 @@ TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* 
     return mine ? len - np : 0u;
 }
 
+template <bool WIDE>
 TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane) {
     const TkTablesView& t = a.t;
     const uint32_t pos = rec & 1023u, len = (rec >> 10) & 127u, slot = rec >> 17;
@@ -572,24 +673,31 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
     uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
     uint32_t holes = 0;
 
-    // ---- short pieces (<= 16 bytes): one lane each; the <= 8-byte ones run the 8-wide variant ---------
+    // ---- pieces of up to 32 bytes: one lane each, parts in registers (8- / 16- / 32-wide by class) ------
     {
-        const bool isshort = have && len <= TKM_SHORT;
-        uint32_t kk[4] = {0u, 0u, 0u, 0u};
-        if (isshort) {
-            if (g + 16 <= (int64_t)a.n_bytes) {
+        const uint32_t cap = WIDE ? 32u : TKM_SHORT;
+        const bool inregs = have && len <= cap;
+        uint32_t kk[WIDE ? 8 : 4];
+        for (int q = 0; q < (WIDE ? 8 : 4); ++q) kk[q] = 0u;
+        if (inregs) {
+            if (g + (int64_t)cap <= (int64_t)a.n_bytes) {
                 wv_load16(a.bytes + g, kk);
+                if (WIDE) wv_load16(a.bytes + g + 16, kk + 4);
             } else {
                 for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)a.bytes[g + q] << (8 * (q & 3));
             }
         }
-        const bool s8 = isshort && len <= 8u, s16 = isshort && len > 8u;
-        if (wv_ballot(s8)) holes += tk_merge_regs<8>(t, s8, kk, len, out);
-        if (wv_ballot(s16)) holes += tk_merge_regs<16>(t, s16, kk, len, out);
+        if (!WIDE) {
+            const bool s8 = inregs && len <= 8u, s16 = inregs && len > 8u;
+            if (wv_ballot(s8)) holes += tk_merge_regs<8>(t, s8, kk, len, out);
+            if (wv_ballot(s16)) holes += tk_merge_regs<16>(t, s16, kk, len, out);
+        } else {
+            if (wv_ballot(inregs)) holes += tk_merge_regs<32>(t, inregs, kk, len, out);
+        }
     }
 
-    // ---- long pieces (17..64 bytes): one at a time, one lane per byte ----------------------------------
-    uint64_t LONGM = wv_ballot(have && len > TKM_SHORT);
+    // ---- longer pieces (33..64 bytes; 17..64 if they ever reach the narrow kernel): one at a time, one lane per byte
+    uint64_t LONGM = wv_ballot(have && len > (WIDE ? 32u : TKM_SHORT));
     while (LONGM) {
         const int src = tk_ctz64(LONGM);
         LONGM &= LONGM - 1ull;

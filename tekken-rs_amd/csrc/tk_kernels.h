@@ -28,8 +28,6 @@ hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, ui
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
                                    hipStream_t s);
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
-// *d_count += number of sampled 1-KB blocks (n_samples of them, evenly spaced) that hold a byte >= 0x80
-hipError_t tk_launch_ascii_probe(const uint8_t* bytes, uint64_t n_bytes, uint32_t n_samples, uint32_t* d_count, hipStream_t s);
 hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
 // doc_info: [n_docs] 16-byte records (TkFlatDocInfo, tk_flat.hip) written by counts, read by assemble
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
@@ -38,7 +36,7 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
                                    uint32_t eos_id, int add_bos, int add_eos, hipStream_t s);
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_miss_a, uint64_t n_miss_b, hipStream_t s);  // totals of the two prefix arrays, read back by the host
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_narrow, uint64_t n_wide, hipStream_t s);  // queued pieces of 2..16 / 17..64 bytes (read back by the host)
 
 // ---- decode path (tk_decode.hip) ----
 struct TkDecodeArgs {

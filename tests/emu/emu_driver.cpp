@@ -99,7 +99,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     const uint64_t n_chunks = (n_bytes + TKF_COMMIT - 1) / TKF_COMMIT;
     std::vector<uint32_t> first_doc(n_chunks + 1, 0), tmp(n_chunks * TKF_STRIDE + 1, 0xDEADBEEFu), kcount(n_chunks + 1, 0);
     std::vector<uint32_t> lstart(n_docs + 1, 0xDEADBEEFu), flags(n_docs + 1, 0), holes(n_docs + 1, 0);
-    std::vector<uint32_t> miss_list(n_chunks * TKF_MISSCAP + 16, 0), miss_count(n_chunks + 1, 0), miss_count_b(n_chunks + 1, 0);
+    std::vector<uint32_t> miss_list(n_chunks * TKF_MISSCAP + 16, 0), miss_count(4 * n_chunks + 1, 0);
     for (uint64_t c = 0; c < n_chunks; ++c) {
         const int64_t lo = (int64_t)c * TKF_COMMIT - TKF_HL;
         uint32_t k = 0;
@@ -120,7 +120,6 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.flags = flags.data();
     fa.miss_list = miss_list.data();
     fa.miss_count = miss_count.data();
-    fa.miss_count_b = miss_count_b.data();
     fa.holes = holes.data();
     fa.dbg_starts = dbg_starts;
     fa.t = T.host_view();
@@ -133,16 +132,16 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
         });
         ops += tkemu::g_wave->n_ops;
-        std::vector<uint64_t> mpfx(n_chunks + 1, 0), mpfx_b(n_chunks + 1, 0);
-        for (uint64_t c = 0; c < n_chunks; ++c) {
-            mpfx[c + 1] = mpfx[c] + miss_count[c];
-            mpfx_b[c + 1] = mpfx_b[c] + miss_count_b[c];
-        }
+        std::vector<uint64_t> mpfx(4 * n_chunks + 1, 0);
+        for (uint64_t e = 0; e < 4 * n_chunks; ++e) mpfx[e + 1] = mpfx[e] + miss_count[e];
         fa.miss_prefix = mpfx.data();
-        fa.miss_prefix_b = mpfx_b.data();
-        const uint64_t waves = (mpfx[n_chunks] + 63) / 64 + (mpfx_b[n_chunks] + 63) / 64;
-        for (uint64_t w = 0; w < waves; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave(fa, w, lane); });
+        const uint64_t n_narrow = mpfx[2 * n_chunks], n_wide = mpfx[4 * n_chunks] - n_narrow;
+        for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
+            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane); });
+            ops += tkemu::g_wave->n_ops;
+        }
+        for (uint64_t w = 0; w * 64 < n_wide; ++w) {
+            tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane); });
             ops += tkemu::g_wave->n_ops;
         }
     }

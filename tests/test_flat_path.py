@@ -119,6 +119,34 @@ def test_emu_flat_every_ascii_byte_pair(small_vocab):
             docs.append(bytes([0x61, b1, b2, 0x31]))
         docs.append(b"'re s")
     _emu_check(small_vocab, docs, False, False)
-    # bytes >= 0x80 only hand the document back
-    flagged = _emu_check(small_vocab, [b"ab", bytes([0x61, 0xC3, 0xA9]), b"cd"], False, False)
-    assert flagged == [1]
+    # multi-byte code points stay on the fast path
+    assert _emu_check(small_vocab, [b"ab", bytes([0x61, 0xC3, 0xA9]), b"cd"], False, False) == []
+
+
+def test_model_utf8():
+    """multi-byte code points in the mask model: classes on all bytes of a char, char-level digit rule, U+017F."""
+    _model_check(helpers.random_unicode_docs(1500, seed=3, max_len=80), region=256)
+    d, o = corpus.generate("mixed", 60, 2048, seed=corpus.BASE_SEED + 2)
+    assert not _model_check(corpus.docs_of(d, o))
+    rng = random.Random(9)
+    alpha = ["a", "S", "1", "\u0663", "\uff13", "'", "\u017f", "s", "!", " ", " ", "\n", "\r", "\u4e2d", "\u00e9", "\U0001f680",
+             "\u00a0", "\u3000", "-", "\t"]
+    for _ in range(150):
+        docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 7, 20]) for _ in range(rng.randint(0, 25))).encode()
+                for _ in range(rng.randint(1, 12))]
+        _model_check(docs, region=rng.choice([256, 1024]))
+
+
+def test_emu_flat_utf8(test_vocab):
+    """the same on the device source: trie classes per lead byte, chars that straddle lanes and regions, multi-byte
+    digit runs (three chars at a time), multi-byte white space at the end of a run, the long s contraction."""
+    d, o = corpus.generate("mixed", 12, 2048, seed=corpus.BASE_SEED + 2)
+    assert _emu_check(test_vocab, corpus.docs_of(d, o)) == []
+    _emu_check(test_vocab, helpers.random_unicode_docs(250, seed=5, max_len=200))
+    rng = random.Random(10)
+    alpha = ["a", "S", "1", "\u0663", "\uff13", "'", "\u017f", "s", "!", " ", " ", "\n", "\r", "\u4e2d", "\u00e9", "\U0001f680",
+             "\u00a0", "\u3000", "-", "\t"]
+    docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 7, 20]) for _ in range(rng.randint(0, 40))).encode()
+            for _ in range(150)]
+    _emu_check(test_vocab, docs)
+    _emu_check(test_vocab, ["x'\u017f y'\u017fz '\u017f".encode(), ("\uff11" * 300).encode(), ("\u4e2d\u6587" * 10 + " ").encode() * 30])

@@ -13,13 +13,46 @@ The pattern is the literal of reference src/tekkenizer.rs:123.
 """
 
 
-def class_masks(buf: bytes):
-    """bit masks over `buf` (ASCII classes; bytes >= 0x80 only set HI)."""
-    m = dict(L=0, N=0, S=0, NL=0, SP=0, AP=0, HI=0, STMD=0, RV=0, E=0, LL=0)
-    for i, b in enumerate(buf):
+def class_masks(buf: bytes, tail: bytes = b""):
+    """bit masks over `buf`.  ASCII classes by value; a multi-byte code point gets the class of its code point on ALL of
+    its bytes (runs stay contiguous), U8C marks continuation bytes.  `tail` = the bytes that follow buf in the stream
+    (a code point that starts inside buf may end there)."""
+    import tk_oracle
+    cls_fn = tk_oracle.lib().tk_oracle_class
+    m = dict(L=0, N=0, S=0, NL=0, SP=0, AP=0, HI=0, STMD=0, RV=0, E=0, LL=0, U8C=0, LS=0, NMB=0)
+    n = len(buf)
+    ext = buf + tail[:4]
+    i = 0
+    while i < n:
+        b = ext[i]
         bit = 1 << i
         if b >= 0x80:
             m["HI"] |= bit
+            if (b & 0xC0) == 0x80:
+                m["U8C"] |= bit           # a continuation byte whose lead was classified (or lies below buf)
+                i += 1
+                continue
+            ln, cp = 1, None
+            if (b & 0xE0) == 0xC0 and i + 1 < len(ext) and (ext[i + 1] & 0xC0) == 0x80:
+                ln, cp = 2, ((b & 0x1F) << 6) | (ext[i + 1] & 0x3F)
+            elif (b & 0xF0) == 0xE0 and i + 2 < len(ext) and all((ext[i + k] & 0xC0) == 0x80 for k in (1, 2)):
+                ln, cp = 3, ((b & 0x0F) << 12) | ((ext[i + 1] & 0x3F) << 6) | (ext[i + 2] & 0x3F)
+            elif (b & 0xF8) == 0xF0 and i + 3 < len(ext) and all((ext[i + k] & 0xC0) == 0x80 for k in (1, 2, 3)):
+                ln, cp = 4, ((b & 0x07) << 18) | ((ext[i + 1] & 0x3F) << 12) | ((ext[i + 2] & 0x3F) << 6) | (ext[i + 3] & 0x3F)
+            c = cls_fn(cp) if cp is not None else 0
+            for k in range(ln):
+                if i + k < n:
+                    kb = 1 << (i + k)
+                    if c == 1:
+                        m["L"] |= kb
+                    elif c == 2:
+                        m["N"] |= kb
+                        m["NMB"] |= kb
+                    elif c == 3:
+                        m["S"] |= kb
+            if b == 0xC5 and i + 1 < len(ext) and ext[i + 1] == 0xBF:
+                m["LS"] |= bit            # U+017F LATIN SMALL LETTER LONG S folds to 's' ((?i) of the pattern)
+            i += 1                        # the continuation bytes are marked by the loop
             continue
         f = b | 0x20
         if 0x61 <= f <= 0x7A:
@@ -42,6 +75,7 @@ def class_masks(buf: bytes):
                 m["SP"] |= bit
         elif b == 0x27:
             m["AP"] |= bit
+        i += 1
     return m
 
 
@@ -65,25 +99,42 @@ def flat_rules(m, DS, n):
         return (x >> 1) & nDE
 
     mL, mN, mS, NL, SP, AP = m["L"], m["N"], m["S"], m["NL"], m["SP"], m["AP"]
+    U8C = m.get("U8C", 0)
+    CS = full & ~U8C                         # first byte of every code point
     mO = full & ~(mL | mN | mS)
+    pOS = p1(mO | SP)
     # alt 1: contractions fire only where a match starts at the apostrophe
-    ok = AP & ~p1(mO | SP)
+    ok = AP & ~pOS
     c2 = ok & n1(m["STMD"])
-    c3 = ok & ~c2 & n1((m["RV"] & n1(m["E"])) | (m["LL"] & n1(m["LL"])))
+    c3 = ok & ~c2 & n1((m["RV"] & n1(m["E"])) | (m["LL"] & n1(m["LL"])) | m.get("LS", 0))
     CEND = ((c2 << 2) | (c3 << 3)) & full
     L1, O1 = p1(mL), p1(mO)
     Lst = mL & ~L1
-    psL = (mL & L1 & CEND) | (Lst & p1(mN | NL)) | (Lst & O1 & p1(p1(mO | SP)))
+    # "the O char before me is not available as alt 2's prefix": it is itself preceded by O or U+0020.  X = O chars
+    # (all their bytes) whose first byte has such a predecessor
+    X = CS & mO & pOS
+    for _ in range(3):
+        X |= p1(X) & U8C
+    psL = (mL & L1 & CEND) | (Lst & p1(mN | NL)) | (Lst & p1(X))
     psO = mO & ~O1 & ~p1(SP)
-    # numbers: every 3rd char of a run (\p{N}{1,3}), by prefix doubling
+    # numbers: every 3rd char of a run (\p{N}{1,3})
     psN = mN & ~p1(mN)
-    M = mN & p1(mN) & p1(p1(mN)) & p1(p1(p1(mN)))
-    k = 3
-    while M:
-        psN |= (psN << k) & M
-        M &= (M << k)
-        k *= 2
-    psN &= full
+    if not m.get("NMB", 0):
+        M = mN & p1(mN) & p1(p1(mN)) & p1(p1(p1(mN)))      # one byte per char: prefix doubling on byte positions
+        k = 3
+        while M:
+            psN |= (psN << k) & M
+            M &= (M << k)
+            k *= 2
+        psN &= full
+    else:
+        def adv1(x):                         # the next char start after each start in x, inside the same run
+            t = (x << 1) & full
+            return ((U8C + t) & ~U8C) & full & mN & nDS
+        cur = psN
+        while cur:
+            cur = adv1(adv1(adv1(cur))) & ~psN
+            psN |= cur
     # white space
     seeds = NL & O1
     Rn = NL & nDS
@@ -98,7 +149,10 @@ def flat_rules(m, DS, n):
         Z |= (Z >> k) & C
         C &= (C >> k)
         k *= 2
-    psS = (SPR & ~cont) | ((Z << 1) & cont & ~Z) | (SPR & ~(cont >> 1) & ~Z & nDE)
+    last = SPR & ~(cont >> 1) & ~Z & nDE     # last byte of a run that is followed by a non-space char
+    for _ in range(3):                       # -> the first byte of that char
+        last = (last & CS) | (n1(last & U8C))
+    psS = (SPR & ~cont) | ((Z << 1) & cont & ~Z) | (last & CS)
     return (psL | psN | psO | psS | DS | 1) & full, dict(SPR=SPR, cont=cont, mN=mN, NL=NL)
 
 
@@ -123,7 +177,7 @@ def flat_split_chunked(data: bytes, offs, region=1024, hl=32, hr=64):
         lo, hi = max(r0, 0), min(r1, n)
         buf = bytes(data[lo:hi])
         shift = lo - r0                      # bytes below 0 do not exist
-        m = {k: v << shift for k, v in class_masks(buf).items()}
+        m = {k: v << shift for k, v in class_masks(buf, bytes(data[hi:hi + 4])).items()}
         DS = 0
         for s in doc_starts[bisect.bisect_left(doc_starts, lo):bisect.bisect_left(doc_starts, hi)]:
             DS |= 1 << (s - r0)
@@ -132,10 +186,12 @@ def flat_split_chunked(data: bytes, offs, region=1024, hl=32, hr=64):
         PS, aux = flat_rules(m, DS, region)
         bad = 0
         a, b = c0 - r0, c1 - r0              # commit range in region coordinates
-        bad |= m["HI"] & (((1 << b) - 1) ^ ((1 << a) - 1))
-        # (A) a digit / CR-LF run that starts below the region and covers the whole left halo
+        # (A) a digit / CR-LF run that starts below the region and covers the whole left halo; the region may begin
+        # inside a code point: its leading continuation bytes have no class and count as part of the run
         if r0 > 0 and not (DS & 1):
-            for run in (aux["mN"], aux["NL"]):
+            u8c = m.get("U8C", 0)
+            lead_cont = u8c & ~(u8c + 1)
+            for run in (aux["mN"] | lead_cont, aux["NL"]):
                 if run & 1:
                     e = 0
                     while e < region and (run >> e) & 1 and not (e > 0 and (DS >> e) & 1):

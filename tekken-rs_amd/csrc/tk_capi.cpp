@@ -53,7 +53,7 @@ struct tk_ctx {
     std::string err;
     TkHostTables host;
     TkTablesView dview;
-    DevBuf t_uc1, t_uc2, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
+    DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
@@ -119,8 +119,13 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
 
     const TkHostTables& h = c->host;
+    if (getenv("TK_DEBUG_LOG"))
+        fprintf(stderr, "[tk] tables: KEY8 %u slots, KEY16 %u slots (hash mode %u, %llu keys), PAIR %u buckets (%llu pairs)\n",
+                h.key8_mask + 1, h.key_mask + 1, h.key_hash_mode, (unsigned long long)h.n_key, h.pair_mask + 1,
+                (unsigned long long)h.n_pairs);
     if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
         (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||
+        (rc = upload(c, c->t_key8, h.key8_tab.data(), h.key8_tab.size() * sizeof(tk_key8_entry))) ||
         (rc = upload(c, c->t_key, h.key_tab.data(), h.key_tab.size() * sizeof(tk_key_entry))) ||
         (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
@@ -131,6 +136,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview = h.host_view();
     c->dview.uc_stage1 = (const uint16_t*)c->t_uc1.p;
     c->dview.uc_stage2 = (const uint32_t*)c->t_uc2.p;
+    c->dview.key8_tab = (const tk_key8_entry*)c->t_key8.p;
     c->dview.key_tab = (const tk_key_entry*)c->t_key.p;
     c->dview.long_tab = (const tk_long_entry*)c->t_long.p;
     c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
@@ -160,7 +166,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
+    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,

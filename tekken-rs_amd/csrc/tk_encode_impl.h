@@ -72,14 +72,32 @@ struct alignas(16) tk_u32x4 { uint32_t x, y, z, w; };
 
 // One probe = ONE round trip: both candidate entries (cuckoo, tk_hash.h) are fetched together with 16-byte loads
 // and compared with bitwise ops; there is no probe loop.
+struct alignas(8) tk_u32x2 { uint32_t x, y; };
+
+// Whole-piece lookup.  A probe costs what its scattered load instructions cost (about one lane per clock through the
+// CU's L1), so: pieces of up to 8 bytes -- most of the text -- take ONE 16-byte load (key, rank and length in one
+// entry of KEY8); pieces of 9..16 bytes a 16-byte + an 8-byte load from KEY16; the second cuckoo location is fetched
+// only by the lanes whose first one did not match (first choices are filled first by the builder).
 TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
-    const uint32_t h = tk_key_hash(k0, k1, k2, k3, len);
-    const tk_u32x4* e1 = reinterpret_cast<const tk_u32x4*>(t.key_tab + (h & t.key_mask));
-    const tk_u32x4* e2 = reinterpret_cast<const tk_u32x4*>(t.key_tab + (tk_hash_alt(h) & t.key_mask));
-    const tk_u32x4 a1 = e1[0], b1 = e1[1], a2 = e2[0], b2 = e2[1];  // a = key, b = {rank, len, pad, pad}
-    const uint32_t d1 = (a1.x ^ k0) | (a1.y ^ k1) | (a1.z ^ k2) | (a1.w ^ k3) | (b1.y ^ len);
-    const uint32_t d2 = (a2.x ^ k0) | (a2.y ^ k1) | (a2.z ^ k2) | (a2.w ^ k3) | (b2.y ^ len);
-    return d1 == 0u ? b1.x : d2 == 0u ? b2.x : TK_RANK_MAX;       // an empty entry has len 0, a probed key len >= 2
+    const uint32_t h = tk_key_hash(t.key_hash_mode, k0, k1, k2, k3, len);
+    if (len <= 8u) {
+        tk_u32x4 e = *reinterpret_cast<const tk_u32x4*>(t.key8_tab + (h & t.key8_mask));   // {k0, k1, rank, len}
+        WV_PIN(e.x); WV_PIN(e.y); WV_PIN(e.z); WV_PIN(e.w);
+        if (((e.x ^ k0) | (e.y ^ k1) | (e.w ^ len)) == 0u) return e.z;
+        e = *reinterpret_cast<const tk_u32x4*>(t.key8_tab + (tk_hash_alt(h) & t.key8_mask));
+        WV_PIN(e.x); WV_PIN(e.y); WV_PIN(e.z); WV_PIN(e.w);
+        return ((e.x ^ k0) | (e.y ^ k1) | (e.w ^ len)) == 0u ? e.z : TK_RANK_MAX;   // an empty entry has len 0
+    }
+    const tk_key_entry* e1 = t.key_tab + (h & t.key_mask);
+    tk_u32x4 a = *reinterpret_cast<const tk_u32x4*>(e1->k);
+    tk_u32x2 b = *reinterpret_cast<const tk_u32x2*>(&e1->rank);   // {rank, len}
+    WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
+    if (((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u) return b.x;
+    const tk_key_entry* e2 = t.key_tab + (tk_hash_alt(h) & t.key_mask);
+    a = *reinterpret_cast<const tk_u32x4*>(e2->k);
+    b = *reinterpret_cast<const tk_u32x2*>(&e2->rank);
+    WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
+    return ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u ? b.x : TK_RANK_MAX;
 }
 
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so
@@ -107,8 +125,18 @@ struct alignas(16) tk_u64x2 { uint64_t x, y; };
 TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
     const uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
     const uint32_t h = tk_pair_hash(a, b);
-    const tk_u64x2 p = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h & t.pair_mask));
-    const tk_u64x2 q = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h) & t.pair_mask));
+    tk_u64x2 p = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h & t.pair_mask));
+    tk_u64x2 q = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h) & t.pair_mask));
+    WV_PIN(p.x); WV_PIN(p.y); WV_PIN(q.x); WV_PIN(q.y);   // both buckets in flight before any compare
+    uint32_t r = TK_RANK_MAX;
+    if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
+    if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
+    if (tk_pair_key(q.x) == key) r = tk_pair_rank(q.x);
+    if (tk_pair_key(q.y) == key) r = tk_pair_rank(q.y);
+    return r;
+}
+
+TK_DEV uint32_t tk_pair_match(const tk_u64x2& p, const tk_u64x2& q, uint64_t key) {
     uint32_t r = TK_RANK_MAX;
     if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
     if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
@@ -120,8 +148,16 @@ TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
 // two independent PAIR probes: all four bucket loads are in flight together
 TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t& r0,
                              uint32_t& r1) {
-    r0 = tk_probe_pair(t, a0, b0);
-    r1 = tk_probe_pair(t, a1, b1);
+    const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
+    const uint32_t h0 = tk_pair_hash(a0, b0), h1 = tk_pair_hash(a1, b1);
+    tk_u64x2 p0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h0 & t.pair_mask));
+    tk_u64x2 q0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h0) & t.pair_mask));
+    tk_u64x2 p1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h1 & t.pair_mask));
+    tk_u64x2 q1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h1) & t.pair_mask));
+    WV_PIN(p0.x); WV_PIN(p0.y); WV_PIN(q0.x); WV_PIN(q0.y);
+    WV_PIN(p1.x); WV_PIN(p1.y); WV_PIN(q1.x); WV_PIN(q1.y);
+    r0 = tk_pair_match(p0, q0, key0);
+    r1 = tk_pair_match(p1, q1, key1);
 }
 
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {

@@ -12,12 +12,16 @@
 // Integer / byte work, no MFMA; bound: HBM (DESIGN.md has the byte accounting).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tk_kernels.h"
 #include "tk_wave_hip.h"
 #include "tk_flat_impl.h"
 
 #define TKF_BLOCK 256
+#ifndef TKF_OCC
+#define TKF_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))  /* 8 waves per SIMD: <= 64 VGPRs */
+#endif
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
                                                                       uint64_t n_chunks, uint32_t* __restrict__ first_doc) {
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
 }
 
-__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
     const int lane = wv_lane();
     uint32_t* lds = lds_all + (threadIdx.x >> 6) * TKF_LDS_WORDS;
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_kernel(TkFlatArgs a) {
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
     TkPolyPow pw;
     pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
+    tk_flat_init_lds(lds, lane);
     for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
@@ -255,7 +260,17 @@ hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, ui
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     uint64_t blocks = (a.n_chunks + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
-    const uint64_t cap = 256ull * 16ull;
+    // persistent waves, chunks strided over them: exactly the blocks that are resident at once (8 per CU at 8 waves per SIMD),
+    // so that no partially filled last round of blocks trails behind
+    static uint64_t cap = 0;
+    if (cap == 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cap = (uint64_t)cus * 8;
+        if (const char* e = getenv("TK_FLAT_BLOCKS")) cap = (uint64_t)atoll(e);
+        if (cap == 0) cap = 1280;
+    }
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();

@@ -38,14 +38,15 @@
 #define TKF_WM 0xFFFFu
 
 // LDS words of one wave
-#define TKF_L_LIST 0                                /* [REGION + 2] piece positions, then the id slot of every piece */
-#define TKF_L_DS (TKF_L_LIST + TKF_REGION + 2)      /* [64] document-start mask words */
+#define TKF_L_LIST 0                                /* u16 [REGION + 4] piece positions, then the id slot of every piece */
+#define TKF_L_DS (TKF_L_LIST + TKF_REGION / 2 + 4)  /* [64] document-start mask words */
 #define TKF_L_PS (TKF_L_DS + 64)                    /* [64] owned piece-start mask words */
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
 #define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
 #define TKF_L_CL (TKF_L_BPFX + 64)                  /* [3 * 64] classes L, N, S of the multi-byte code points */
-#define TKF_LDS_WORDS (TKF_L_CL + 3 * 64)
+#define TKF_L_KM (TKF_L_CL + 3 * 64)                 /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
+#define TKF_LDS_WORDS (TKF_L_KM + 17 * 4)
 
 
 // ------------------------------------------------------------------------------------------
@@ -245,6 +246,17 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
 // ------------------------------------------------------------------------------------------
 // one chunk
 // ------------------------------------------------------------------------------------------
+// once per wave, before its first chunk: the key byte masks
+TK_DEV void tk_flat_init_lds(uint32_t* lds, int lane) {
+    if (lane <= 16) {
+        for (int q = 0; q < 4; ++q) {
+            const int keep = lane - 4 * q;
+            lds[TKF_L_KM + 4 * lane + q] = keep >= 4 ? 0xFFFFFFFFu : keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u);
+        }
+    }
+    wv_lds_sync();
+}
+
 TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
 TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds, const TkPolyPow& pw) {
@@ -254,7 +266,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     const int64_t c0 = (int64_t)c * TKF_COMMIT, r0 = c0 - TKF_HL, r1 = r0 + TKF_REGION;
     const int64_t c1 = c0 + TKF_COMMIT < n ? c0 + TKF_COMMIT : n;
     const int ca = TKF_HL, cb = (int)(c1 - r0);  // commit range in region coordinates
-    uint32_t* list = lds + TKF_L_LIST;
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds + TKF_L_LIST);
 
     // ---- 1. load 16 bytes per lane, classify ---------------------------------------------------
     uint32_t x[4] = {0u, 0u, 0u, 0u};
@@ -399,7 +411,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         uint32_t w = PSlist, idx = pfx_all;
         while (wv_ballot(w != 0u)) {
             if (w) {
-                list[idx++] = (uint32_t)(16 * lane + __builtin_ctz(w));
+                list[idx++] = (uint16_t)(16 * lane + __builtin_ctz(w));
                 w &= w - 1u;
             }
         }
@@ -423,7 +435,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         uint32_t pos = 0, len = 1;
         if (act) {
             pos = list[idx];
-            len = list[idx + 1] - pos;
+            len = (uint32_t)list[idx + 1] - pos;
         }
         uint32_t r = 0;
         bool toolong = false;
@@ -432,9 +444,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         } else if (act) {
             if (len > 64u) {
                 toolong = true;
-            } else if (len == 1u) {
-                r = rbytes[pos];                            // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
             } else if (len <= 16u) {
+                // the piece's first 16 bytes (a single byte takes its rank from here too)
                 uint32_t kk[4] = {0u, 0u, 0u, 0u};
                 const int64_t g = r0 + (int64_t)pos;
                 if (g + 16 <= n) {
@@ -442,12 +453,13 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 } else {
                     for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)rbytes[pos + q] << (8 * (q & 3));
                 }
-                // zero the bytes past the piece
-                for (int q = 0; q < 4; ++q) {
-                    const int keep = (int)len - 4 * q;
-                    kk[q] = keep >= 4 ? kk[q] : keep <= 0 ? 0u : (kk[q] & ((1u << (8 * keep)) - 1u));
-                }
-                r = tk_probe_key(t, kk[0], kk[1], kk[2], kk[3], len);
+                // zero the bytes past the piece (masks by length from LDS)
+                const uint32_t* km = lds + TKF_L_KM + 4u * len;
+                kk[0] &= km[0]; kk[1] &= km[1]; kk[2] &= km[2]; kk[3] &= km[3];
+                // rank of a single byte is the byte (src/tekkenizer.rs:793-798); longer pieces: exact-key probe
+                if (a.dbg_ablate & 64) r = (kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) & 0xFFFFu;                       // timing: no hash, no table
+                else if (a.dbg_ablate & 128) r = tk_key_hash(t.key_hash_mode, kk[0], kk[1], kk[2], kk[3], len) & 0xFFFFu;  // timing: no table
+                else r = len == 1u ? kk[0] : tk_probe_key(t, kk[0], kk[1], kk[2], kk[3], len);
             } else {
                 uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
                 for (uint32_t q = 0; q < len; ++q) {
@@ -486,7 +498,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
-            list[idx] = slot;                               // step 7 looks the slot of a document start up here
+            list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
             if (!miss && !(a.dbg_ablate & 4)) tmp[slot] = r + t.num_special;
         }
     }

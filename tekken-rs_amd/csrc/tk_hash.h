@@ -11,11 +11,14 @@
 //
 // KEY/LONG serve the whole-piece shortcut, PAIR/PAIR2 serve the merge loop.
 //
-// KEY and PAIR are CUCKOO tables: every key has exactly two candidate locations (slot / bucket h & mask and
-// rotl(h, 16) & mask), both are fetched together, so a probe is ONE round trip whether it hits or misses --
-// no probe loop, no divergence between the 64 lanes of a wave (with linear probing the wave waited for its
-// longest chain of dependent loads).  KEY: one 32-byte entry per slot, load <= 1/3.  PAIR: buckets of two
-// 8-byte entries (one 16-byte load per bucket), load <= 1/2.
+// KEY8 / KEY16 and PAIR are CUCKOO tables: every key has exactly two candidate locations (slot / bucket h & mask
+// and rotl(h, 16) & mask) -- no probe loop (with linear probing a wave waited for the longest chain of its 64 lanes).
+// What a wave-wide probe costs on CDNA is the NUMBER OF SCATTERED LOAD INSTRUCTIONS (the CU's L1 takes about one lane
+// per clock), so the layouts minimise that: KEY8 (pieces of 2..8 bytes, most of the text) has 16-byte entries
+// {k0, k1, rank, len} -- ONE 16-byte load fetches key, rank and length; KEY16 (9..16 bytes) has 32-byte entries
+// (16-byte + 8-byte load).  The builder fills first choices first (load <= 1/3), the second location is fetched only
+// by the lanes whose first one mismatched.  PAIR: buckets of two 8-byte entries (one 16-byte load per bucket), both
+// buckets fetched together (the merge kernel is latency-, not issue-bound), load <= 1/2.
 #ifndef TK_HASH_H
 #define TK_HASH_H
 #include <stdint.h>
@@ -34,11 +37,17 @@
 #define TK_POLY_P1 0x01000193u           /* odd => invertible mod 2^32 */
 #define TK_POLY_P2 0x9E3779B1u
 
-struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 2..16 bytes, exact 128-bit key */
+struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 9..16 bytes, exact 128-bit key */
     uint32_t k[4];                       /* piece bytes little-endian, zero padded */
     uint32_t rank;
-    uint32_t len;                        /* 2..16 */
+    uint32_t len;                        /* 9..16 */
     uint32_t pad[2];
+};
+
+struct alignas(16) tk_key8_entry {       /* 16 B, len == 0 <=> empty: pieces of 2..8 bytes */
+    uint32_t k[2];                       /* piece bytes little-endian, zero padded */
+    uint32_t rank;
+    uint32_t len;                        /* 2..8 */
 };
 
 struct alignas(16) tk_long_entry {       /* 16 B, len == 0 <=> empty */
@@ -53,7 +62,21 @@ TK_HD uint32_t tk_fmix32(uint32_t h) {
     return h;
 }
 
-TK_HD uint32_t tk_key_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+TK_HD uint32_t tk_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+// Hash of a KEY piece (zero-padded 16 bytes + length).  mode 0 (default): the upper 8 bytes are folded into the lower
+// ones before two multiplies + one finalizer multiply -- 32-bit multiplies are quarter rate on CDNA and this hash runs
+// once per piece of text.  mode 1: one multiply per dword and the full finalizer; the table builder falls back to it
+// if a vocabulary cannot be placed with mode 0 (the fold makes structured collisions possible, the cuckoo placement
+// tolerates two keys per hash value but not three).
+TK_HD uint32_t tk_key_hash(uint32_t mode, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    if (mode == 0u) {
+        const uint32_t x = (k0 ^ tk_rotl32(k2, 13)) * 0x9E3779B1u;
+        const uint32_t y = (k1 ^ tk_rotl32(k3, 17) ^ (len << 24)) * 0x85EBCA77u;
+        uint32_t h = x ^ tk_rotl32(y, 15);
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
+        return h;
+    }
     uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du + k3 * 0x27D4EB2Fu + len * 0x165667B1u;
     return tk_fmix32(h);
 }

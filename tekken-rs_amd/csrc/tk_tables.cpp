@@ -28,14 +28,17 @@ TkTablesView TkHostTables::host_view() const {
     TkTablesView v;
     v.uc_stage1 = uc_stage1.data();
     v.uc_stage2 = uc_stage2.data();
+    v.key8_tab = key8_tab.data();
     v.key_tab = key_tab.data();
     v.long_tab = long_tab.data();
     v.pair_tab = pair_tab.data();
     v.pair2 = pair2.data();
     v.blob = blob.data();
+    v.key8_mask = key8_mask;
     v.key_mask = key_mask;
     v.long_mask = long_mask;
     v.pair_mask = pair_mask;
+    v.key_hash_mode = key_hash_mode;
     v.n_ranks = n_ranks;
     v.num_special = num_special;
     v.bos_id = bos_id;
@@ -131,32 +134,52 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         }
     }
 
-    // KEY: cuckoo placement, one entry per slot, two candidate slots per key, load <= 1/3 (grown on failure)
-    for (uint32_t kcap = pow2_at_least(3 * n_key + 1);; kcap <<= 1) {
-        out.key_mask = kcap - 1;
-        out.key_tab.assign(kcap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
-        bool ok = true;
-        uint32_t rnd = 0x9E3779B9u;
-        for (const tk_key_entry& e0 : key_entries) {
-            tk_key_entry e = e0;
-            uint32_t avoid = 0xFFFFFFFFu;
-            int kicks = 0;
-            for (;; ++kicks) {
-                const uint32_t h = tk_key_hash(e.k[0], e.k[1], e.k[2], e.k[3], e.len);
-                const uint32_t s1 = h & out.key_mask, s2 = tk_hash_alt(h) & out.key_mask;
-                if (out.key_tab[s1].len == 0) { out.key_tab[s1] = e; break; }
-                if (out.key_tab[s2].len == 0) { out.key_tab[s2] = e; break; }
-                if (kicks >= 500) { ok = false; break; }
-                rnd = rnd * 1664525u + 1013904223u;
-                uint32_t victim = (rnd >> 16) & 1u ? s2 : s1;
-                if (victim == avoid) victim = victim == s1 ? s2 : s1;   // do not bounce straight back
-                std::swap(e, out.key_tab[victim]);
-                avoid = victim;
+    // KEY8 (2..8 bytes, 16-byte entries) and KEY16 (9..16 bytes, 32-byte entries): cuckoo placement, one entry per slot,
+    // two candidate slots per key, load <= 1/3, first choices filled first.  The cheap hash (mode 0) is tried at the
+    // initial capacity and at twice that; if the vocabulary cannot be placed (structured collisions of the fold), the
+    // strong hash (mode 1) is used and the tables grown until they fit.
+    {
+        std::vector<tk_key_entry> e8, e16;
+        for (const tk_key_entry& e : key_entries) (e.len <= 8 ? e8 : e16).push_back(e);
+        auto place = [&](const std::vector<tk_key_entry>& ents, uint32_t mode, uint32_t cap, std::vector<tk_key_entry>& tab) -> bool {
+            const uint32_t mask = cap - 1;
+            tab.assign(cap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
+            uint32_t rnd = 0x9E3779B9u;
+            for (const tk_key_entry& e0 : ents) {
+                tk_key_entry e = e0;
+                uint32_t avoid = 0xFFFFFFFFu;
+                for (int kicks = 0;; ++kicks) {
+                    const uint32_t h = tk_key_hash(mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len);
+                    const uint32_t s1 = h & mask, s2 = tk_hash_alt(h) & mask;
+                    if (tab[s1].len == 0) { tab[s1] = e; break; }
+                    if (tab[s2].len == 0) { tab[s2] = e; break; }
+                    if (kicks >= 500) return false;
+                    rnd = rnd * 1664525u + 1013904223u;
+                    uint32_t victim = (rnd >> 16) & 1u ? s2 : s1;
+                    if (victim == avoid) victim = victim == s1 ? s2 : s1;   // do not bounce straight back
+                    std::swap(e, tab[victim]);
+                    avoid = victim;
+                }
             }
-            if (!ok) break;
+            return true;
+        };
+        const uint32_t cap8_0 = pow2_at_least(3 * e8.size() + 1), cap16_0 = pow2_at_least(3 * e16.size() + 1);
+        std::vector<tk_key_entry> t8;
+        bool done = false;
+        for (int attempt = 0; !done; ++attempt) {
+            const uint32_t mode = attempt < 2 ? 0u : 1u;
+            const int grow = attempt < 2 ? attempt : attempt - 2;
+            if (((uint64_t)cap8_0 << grow) > (1ull << 30) || ((uint64_t)cap16_0 << grow) > (1ull << 30)) {
+                err = "could not place the vocabulary in the KEY tables";
+                return TK_ERR_INVALID_CONFIG;
+            }
+            out.key_hash_mode = mode;
+            out.key8_mask = (cap8_0 << grow) - 1;
+            out.key_mask = (cap16_0 << grow) - 1;
+            done = place(e8, mode, cap8_0 << grow, t8) && place(e16, mode, cap16_0 << grow, out.key_tab);
         }
-        if (ok) break;
-        if (kcap >= (1u << 30)) { err = "could not place the vocabulary in the KEY table"; return TK_ERR_INVALID_CONFIG; }
+        out.key8_tab.resize(t8.size());
+        for (size_t i = 0; i < t8.size(); ++i) out.key8_tab[i] = tk_key8_entry{{t8[i].k[0], t8[i].k[1]}, t8[i].rank, t8[i].len};
     }
 
     // PAIR: every split of every token whose halves are both tokens

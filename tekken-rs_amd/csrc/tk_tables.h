@@ -17,12 +17,14 @@
 struct TkTablesView {
     const uint16_t* uc_stage1;       // Unicode class trie, stage 1 (cp >> 7 -> block)
     const uint32_t* uc_stage2;       // stage 2: 16 x 2-bit classes per word
-    const tk_key_entry* key_tab;     // whole pieces of 2..16 bytes (exact key), cuckoo: slots h & key_mask, alt(h) & key_mask
+    const tk_key8_entry* key8_tab;   // whole pieces of 2..8 bytes (exact key), cuckoo: slots h & key8_mask, alt(h) & key8_mask
+    const tk_key_entry* key_tab;     // whole pieces of 9..16 bytes (exact key), cuckoo: slots h & key_mask, alt(h) & key_mask
     const tk_long_entry* long_tab;   // whole pieces of >= 17 bytes
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
     const uint8_t* blob;             // token bytes, for verifying LONG hits
-    uint32_t key_mask, long_mask, pair_mask;
+    uint32_t key8_mask, key_mask, long_mask, pair_mask;
+    uint32_t key_hash_mode;          // tk_key_hash mode the KEY table was built with
     uint32_t n_ranks, num_special, bos_id, eos_id;
     uint32_t p1inv, p2inv;           // inverses of the polynomial bases mod 2^32
 };
@@ -32,11 +34,12 @@ struct TkHostTables {
     std::vector<uint32_t> offs;
     std::vector<uint16_t> uc_stage1;
     std::vector<uint32_t> uc_stage2;
+    std::vector<tk_key8_entry> key8_tab;
     std::vector<tk_key_entry> key_tab;
     std::vector<tk_long_entry> long_tab;
     std::vector<uint64_t> pair_tab;
     std::vector<uint32_t> pair2;
-    uint32_t key_mask = 0, long_mask = 0, pair_mask = 0;
+    uint32_t key8_mask = 0, key_mask = 0, long_mask = 0, pair_mask = 0, key_hash_mode = 0;
     uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
     uint32_t p1inv = 0, p2inv = 0;
     uint64_t n_pairs = 0, n_key = 0, n_long = 0;

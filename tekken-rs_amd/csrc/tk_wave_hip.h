@@ -97,4 +97,11 @@ TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {
     return x;
 }
 
+// bytes sh..sh+3 of the 8 bytes {hi:lo} (v_alignbyte_b32), sh in 0..3
+TK_DEV uint32_t wv_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+
+// "this value is needed HERE": keeps the compiler from sinking the load that produces it behind a later branch (it
+// otherwise turns independent loads into a chain of conditional ones -- each a full memory round trip)
+#define WV_PIN(x) asm volatile("" : "+v"(x))
+
 #endif

@@ -129,6 +129,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         tkemu::run_wave([&](int lane) {
             TkPolyPow pw;
             pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
+            tk_flat_init_lds(lds.data(), lane);
             for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
         });
         ops += tkemu::g_wave->n_ops;

@@ -225,4 +225,10 @@ TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {
     return s;
 }
 
+TK_DEV uint32_t wv_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3u)));
+}
+
+#define WV_PIN(x) ((void)(x))
+
 #endif

@@ -288,19 +288,16 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     const uint64_t n_chunks = (n_bytes + TKF_COMMIT - 1) / TKF_COMMIT;
     TK_HIP(c, c->f_first.reserve((n_chunks + 1) * 4));
     TK_HIP(c, c->f_tmp.reserve((n_chunks * TKF_STRIDE + 64) * 4));
-    TK_HIP(c, c->f_k.reserve((n_chunks + 1) * 4));
-    TK_HIP(c, c->f_P.reserve((n_chunks + 2) * 8));
     TK_HIP(c, c->f_lstart.reserve((n_docs + 1) * 4));
-    TK_HIP(c, c->f_flags.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->f_flags.reserve(2 * (n_docs + 1) * 4));   // flags | holes (one memset)
     TK_HIP(c, c->f_todo.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->f_miss.reserve((n_chunks * TKF_MISSCAP + 64) * 4));  // worst case; only the used records are ever touched
-    TK_HIP(c, c->f_mcnt.reserve((4 * n_chunks + 1) * 4));
-    TK_HIP(c, c->f_mpfx.reserve((4 * n_chunks + 2) * 8));
-    TK_HIP(c, c->f_holes.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->f_mcnt.reserve((5 * n_chunks + 1) * 4));   // 4 C miss counts (class-major) | C slot counts (one scan)
+    TK_HIP(c, c->f_mpfx.reserve((5 * n_chunks + 2) * 8));
     TK_HIP(c, c->f_info.reserve((n_docs + 1) * 16));
     TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
-    const uint64_t scan_n = n_docs > 4 * n_chunks ? n_docs : 4 * n_chunks;
+    const uint64_t scan_n = n_docs > 5 * n_chunks ? n_docs : 5 * n_chunks;
     TK_HIP(c, c->block_sums.reserve((scan_n / 2048 + 4) * 8));
 
     TkFlatArgs fa;
@@ -312,34 +309,50 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.n_chunks = n_chunks;
     fa.first_doc = (const uint32_t*)c->f_first.p;
     fa.tmp = (uint32_t*)c->f_tmp.p;
-    fa.kcount = (uint32_t*)c->f_k.p;
+    fa.kcount = (uint32_t*)c->f_mcnt.p + 4 * n_chunks;
     fa.lstart = (uint32_t*)c->f_lstart.p;
     fa.flags = (uint32_t*)c->f_flags.p;
     fa.miss_list = (uint32_t*)c->f_miss.p;
     fa.miss_count = (uint32_t*)c->f_mcnt.p;
     fa.miss_prefix = (const uint64_t*)c->f_mpfx.p;
-    fa.holes = (uint32_t*)c->f_holes.p;
+    fa.holes = (uint32_t*)c->f_flags.p + (n_docs + 1);
     fa.t = c->dview;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
 
+    // One host sync per batch in the common case.  Everything that depends on device-side counts stays on the device:
+    // the merge kernels are persistent, the output buffer takes its upper bound (a document cannot produce more ids
+    // than bytes + 2), and the handed-back documents are only COUNTED at first -- if there are any, the per-document
+    // kernels run afterwards and counts / scan / assembly are redone.
+    const uint32_t extra = (uint32_t)((add_bos ? 1 : 0) + (add_eos ? 1 : 0));
+    uint64_t* d_pfx = (uint64_t*)c->f_mpfx.p;                  // prefix sums over [4 C miss counts | C slot counts]
+    const uint64_t* d_P = d_pfx + 4 * n_chunks;                // chunk slot prefix sums (offset by the miss total: only differences are used)
+    TK_HIP(c, c->out_ids.reserve((n_bytes + 2 * n_docs + 64) * 4));
     TK_HIP(c, hipEventRecord(c->ev[3], s));
     TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, s));
-    TK_HIP(c, hipMemsetAsync(c->f_flags.p, 0, (n_docs + 1) * 4, s));
-    TK_HIP(c, hipMemsetAsync(c->f_holes.p, 0, (n_docs + 1) * 4, s));
+    TK_HIP(c, hipMemsetAsync(c->f_flags.p, 0, 2 * (n_docs + 1) * 4, s));   // flags | holes
     TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, s));
     TK_HIP(c, hipEventRecord(c->ev[0], s));
     TK_HIP(c, tk_launch_flat(fa, s));
     TK_HIP(c, hipEventRecord(c->ev[1], s));
-    TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
-    TK_HIP(c, tk_launch_scan(fa.miss_count, 4 * n_chunks, (uint64_t*)c->f_mpfx.p, (uint64_t*)c->block_sums.p, s));
-    TK_HIP(c, tk_launch_scan(fa.kcount, n_chunks, (uint64_t*)c->f_P.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_merge(fa, s));
+    uint64_t total = 0;
     uint32_t n_todo = 0;
-    uint64_t n_narrow = 0, n_all = 0;   // queued pieces of 2..16 bytes / of all classes
-    TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(&n_narrow, (uint64_t*)c->f_mpfx.p + 2 * n_chunks, 8, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(&n_all, (uint64_t*)c->f_mpfx.p + 4 * n_chunks, 8, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipStreamSynchronize(s));
-    TK_HIP(c, tk_launch_merge(fa, n_narrow, n_all - n_narrow, s));
+    auto finish = [&](int final_pass) -> int {
+        TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, d_P, fa.lstart, fa.flags, fa.holes, extra,
+                                        (uint32_t*)c->counts.p, c->f_info.p, final_pass, (uint32_t*)c->counters.p + 4, s));
+        TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
+        TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
+                                          (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id,
+                                          c->host.eos_id, add_bos, add_eos, s));
+        TK_HIP(c, hipEventRecord(c->ev[2], s));
+        TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+        if (!final_pass) TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        return TK_OK;
+    };
+    int rc = finish(0);
+    if (rc != TK_OK) return rc;
     c->n_flagged = n_todo;
     c->n_long_docs = 0;
     if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,
@@ -348,6 +361,8 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         // the per-document path over the handed-back documents: pass 1 (mode 3), then pass 2 for its own deferrals
         TK_HIP(c, c->staging.reserve((n_bytes + 2 * n_docs + 64) * 4));
         TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
+        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 4, 0, 4, s));
+        TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
         TkEncodeArgs a;
         memset(&a, 0, sizeof(a));
         a.bytes = d_bytes;
@@ -374,19 +389,9 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
             int rc2 = run_pass2(c, a, d_offs, n_def, s);
             if (rc2 != TK_OK) return rc2;
         }
+        rc = finish(1);
+        if (rc != TK_OK) return rc;
     }
-    TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, (const uint64_t*)c->f_P.p, fa.lstart, fa.flags,
-                                    fa.holes, (uint32_t)((add_bos ? 1 : 0) + (add_eos ? 1 : 0)), (uint32_t*)c->counts.p, c->f_info.p, s));
-    TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
-    uint64_t total = 0;
-    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipStreamSynchronize(s));
-    TK_HIP(c, c->out_ids.reserve((total + 64) * 4));
-    TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
-                                      (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id, c->host.eos_id,
-                                      add_bos, add_eos, s));
-    TK_HIP(c, hipEventRecord(c->ev[2], s));
-    TK_HIP(c, hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[3], c->ev[2]);
     *n_ids = total;

@@ -50,14 +50,19 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
     for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
+// persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are)
 __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    tk_merge_wave<false>(a, wave, wv_lane());
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
+    const uint64_t total = a.miss_prefix[2 * a.n_chunks];
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane());
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    tk_merge_wave<true>(a, wave, wv_lane());
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
+    const uint64_t total = a.miss_prefix[4 * a.n_chunks] - a.miss_prefix[2 * a.n_chunks];
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<true>(a, w, wv_lane());
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
@@ -97,14 +102,27 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_
                                                                     const uint32_t* __restrict__ flags,
                                                                     const uint32_t* __restrict__ holes, uint32_t extra,
                                                                     uint32_t* __restrict__ counts,
-                                                                    TkFlatDocInfo* __restrict__ info) {
+                                                                    TkFlatDocInfo* __restrict__ info, int final_pass,
+                                                                    uint32_t* __restrict__ n_flagged) {
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
+    const bool flagged = d < n_docs && flags[d] != 0u;
+    if (!final_pass) {
+        // first (optimistic) pass: count the handed-back documents; the host redoes counts / scan / assembly after the
+        // per-document kernels if there are any.  Until then they stand in as empty documents.
+        const uint64_t m = __ballot(flagged);
+        if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(n_flagged, (uint32_t)__builtin_popcountll(m));
+    }
     if (d >= n_docs) return;
     TkFlatDocInfo di;
-    if (flags[d]) {  // a flagged document keeps the count of the per-document kernel
-        di.src = doc_offs[d] + 2 * d;
-        di.n_slots = counts[d];
-        di.n_first = 0xFFFFFFFFu;
+    if (flagged) {
+        if (final_pass) {  // the document keeps the count of the per-document kernel, the assembly copies it from staging
+            di.src = doc_offs[d] + 2 * d;
+            di.n_slots = counts[d];
+            di.n_first = 0xFFFFFFFFu;
+        } else {
+            counts[d] = extra;
+            di.src = 0; di.n_slots = 0; di.n_first = 0;
+        }
         info[d] = di;
         return;
     }
@@ -276,10 +294,15 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_narrow, uint64_t n_wide, hipStream_t s) {
-    const uint64_t w1 = (n_narrow + 63) / 64, w2 = (n_wide + 63) / 64;
-    if (w1) hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)((w1 + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
-    if (w2) hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)((w2 + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64))), dim3(TKF_BLOCK), 0, s, a);
+hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
+    if (a.n_chunks == 0) return hipSuccess;
+    // persistent grids (the number of queued pieces stays on the device); never more blocks than sub-queues could fill
+    const uint64_t cap = 256ull * 8ull;
+    uint64_t b1 = (a.n_chunks * 4 + 3) / 4, b2 = (a.n_chunks + 3) / 4;
+    if (b1 > cap) b1 = cap;
+    if (b2 > cap / 2) b2 = cap / 2;
+    hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKF_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -291,10 +314,10 @@ hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t*
 
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
                                  const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,
-                                 uint32_t extra, uint32_t* counts, void* doc_info, hipStream_t s) {
+                                 uint32_t extra, uint32_t* counts, void* doc_info, int final_pass, uint32_t* n_flagged, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_flat_counts_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs, n_bytes,
-                       n_chunks, P, lstart, flags, holes, extra, counts, (TkFlatDocInfo*)doc_info);
+                       n_chunks, P, lstart, flags, holes, extra, counts, (TkFlatDocInfo*)doc_info, final_pass, n_flagged);
     return hipGetLastError();
 }
 

@@ -32,11 +32,11 @@ hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t*
 // doc_info: [n_docs] 16-byte records (TkFlatDocInfo, tk_flat.hip) written by counts, read by assemble
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
                                  const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,
-                                 uint32_t extra, uint32_t* counts, void* doc_info, hipStream_t s);
+                                 uint32_t extra, uint32_t* counts, void* doc_info, int final_pass, uint32_t* n_flagged, hipStream_t s);
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
                                    uint32_t eos_id, int add_bos, int add_eos, hipStream_t s);
-hipError_t tk_launch_merge(const TkFlatArgs& a, uint64_t n_narrow, uint64_t n_wide, hipStream_t s);  // queued pieces of 2..16 / 17..64 bytes (read back by the host)
+hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
 
 // ---- decode path (tk_decode.hip) ----
 struct TkDecodeArgs {

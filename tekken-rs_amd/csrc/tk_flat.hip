@@ -297,7 +297,7 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     // persistent grids (the number of queued pieces stays on the device); never more blocks than sub-queues could fill
-    const uint64_t cap = 256ull * 8ull;
+    const uint64_t cap = 16384;   // many more blocks than are resident: the rounds a wave needs vary, small units balance better
     uint64_t b1 = (a.n_chunks * 4 + 3) / 4, b2 = (a.n_chunks + 3) / 4;
     if (b1 > cap) b1 = cap;
     if (b2 > cap / 2) b2 = cap / 2;

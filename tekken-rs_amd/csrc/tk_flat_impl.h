@@ -328,7 +328,12 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         m.nmb = wv_ballot(nmb) != 0ull;
     }
     if (a.dbg_ablate & 16) {
-        if (lane == 0) a.kcount[c] = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
+        // (keeps the work alive without producing slot counts: the downstream kernels must see an empty chunk)
+        const uint32_t v = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
+        if (lane == 0) {
+            a.kcount[c] = v == 0xFFFFFFFFu ? 1u : 0u;
+            for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
+        }
         return;
     }
 
@@ -358,7 +363,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     uint32_t SPR, cont;
     const uint32_t PS = tkf_rules(m, DS, lane, &SPR, &cont);
     if (a.dbg_ablate & 8) {
-        if (lane == 0) a.kcount[c] = PS + SPR + cont;
+        if (lane == 0) {
+            a.kcount[c] = (PS + SPR + cont) == 0xFFFFFFFFu ? 1u : 0u;
+            for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
+        }
         return;
     }
     const uint32_t commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;

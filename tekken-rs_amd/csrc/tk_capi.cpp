@@ -120,9 +120,9 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 
     const TkHostTables& h = c->host;
     if (getenv("TK_DEBUG_LOG"))
-        fprintf(stderr, "[tk] tables: KEY8 %u slots, KEY16 %u slots (hash mode %u, %llu keys), PAIR %u buckets (%llu pairs)\n",
-                h.key8_mask + 1, h.key_mask + 1, h.key_hash_mode, (unsigned long long)h.n_key, h.pair_mask + 1,
-                (unsigned long long)h.n_pairs);
+        fprintf(stderr, "[tk] tables: KEY8 %u slots, KEY16 %u slots (hash mode %u, %llu keys, %llu in their second slot, %llu slots flagged), PAIR %u buckets (%llu pairs)\n",
+                h.key8_mask + 1, h.key_mask + 1, h.key_hash_mode, (unsigned long long)h.n_key, (unsigned long long)h.n_key_second,
+                (unsigned long long)h.n_key_spill_slots, h.pair_mask + 1, (unsigned long long)h.n_pairs);
     if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
         (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||
         (rc = upload(c, c->t_key8, h.key8_tab.data(), h.key8_tab.size() * sizeof(tk_key8_entry))) ||

@@ -80,24 +80,30 @@ struct alignas(8) tk_u32x2 { uint32_t x, y; };
 // only by the lanes whose first one did not match (first choices are filled first by the builder).
 TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
     const uint32_t h = tk_key_hash(t.key_hash_mode, k0, k1, k2, k3, len);
-    if (len <= 8u) {
-        tk_u32x4 e = *reinterpret_cast<const tk_u32x4*>(t.key8_tab + (h & t.key8_mask));   // {k0, k1, rank, len}
-        WV_PIN(e.x); WV_PIN(e.y); WV_PIN(e.z); WV_PIN(e.w);
-        if (((e.x ^ k0) | (e.y ^ k1) | (e.w ^ len)) == 0u) return e.z;
-        e = *reinterpret_cast<const tk_u32x4*>(t.key8_tab + (tk_hash_alt(h) & t.key8_mask));
-        WV_PIN(e.x); WV_PIN(e.y); WV_PIN(e.z); WV_PIN(e.w);
-        return ((e.x ^ k0) | (e.y ^ k1) | (e.w ^ len)) == 0u ? e.z : TK_RANK_MAX;   // an empty entry has len 0
-    }
-    const tk_key_entry* e1 = t.key_tab + (h & t.key_mask);
-    tk_u32x4 a = *reinterpret_cast<const tk_u32x4*>(e1->k);
-    tk_u32x2 b = *reinterpret_cast<const tk_u32x2*>(&e1->rank);   // {rank, len}
+    // KEY8 and KEY16 lanes issue their loads TOGETHER and wait once: a wave that holds pieces of both kinds would
+    // otherwise walk the two tables one after the other, every step a full memory round trip for the whole wave
+    const bool s8 = len <= 8u;
+    const uint8_t* p1 = s8 ? reinterpret_cast<const uint8_t*>(t.key8_tab + (h & t.key8_mask))
+                           : reinterpret_cast<const uint8_t*>(t.key_tab + (h & t.key_mask));
+    tk_u32x4 a = *reinterpret_cast<const tk_u32x4*>(p1);          // KEY8: {k0, k1, rank, len}; KEY16: {k0, k1, k2, k3}
+    tk_u32x2 b;
+    b.x = 0u; b.y = 0u;
+    if (!s8) b = *reinterpret_cast<const tk_u32x2*>(p1 + 16);     // KEY16: {rank, len}
     WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
-    if (((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u) return b.x;
-    const tk_key_entry* e2 = t.key_tab + (tk_hash_alt(h) & t.key_mask);
-    a = *reinterpret_cast<const tk_u32x4*>(e2->k);
-    b = *reinterpret_cast<const tk_u32x2*>(&e2->rank);
+    const uint32_t lw = s8 ? a.w : b.y;                          // len | spill flag of the slot
+    uint32_t d = s8 ? ((a.x ^ k0) | (a.y ^ k1)) : ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3));
+    d |= (lw & ~TK_KEY_SPILL) ^ len;
+    if (d == 0u) return s8 ? a.z : b.x;
+    if (!(lw & TK_KEY_SPILL)) return TK_RANK_MAX;                // nothing spilled from this slot: a definite miss
+    // second location (first choices are filled first by the builder: few lanes get here)
+    const uint32_t h2 = tk_hash_alt(h);
+    const uint8_t* p2 = s8 ? reinterpret_cast<const uint8_t*>(t.key8_tab + (h2 & t.key8_mask))
+                           : reinterpret_cast<const uint8_t*>(t.key_tab + (h2 & t.key_mask));
+    a = *reinterpret_cast<const tk_u32x4*>(p2);
+    if (!s8) b = *reinterpret_cast<const tk_u32x2*>(p2 + 16);
     WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
-    return ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | (b.y ^ len)) == 0u ? b.x : TK_RANK_MAX;
+    d = s8 ? ((a.x ^ k0) | (a.y ^ k1) | ((a.w & ~TK_KEY_SPILL) ^ len)) : ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | ((b.y & ~TK_KEY_SPILL) ^ len));
+    return d == 0u ? (s8 ? a.z : b.x) : TK_RANK_MAX;              // an empty entry has len 0
 }
 
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so

@@ -36,6 +36,8 @@
 #define TK_PAIR_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define TK_POLY_P1 0x01000193u           /* odd => invertible mod 2^32 */
 #define TK_POLY_P2 0x9E3779B1u
+#define TK_KEY_SPILL 0x80000000u         /* in the len word of a KEY8 / KEY16 slot: some key whose FIRST choice is this slot lives in its second
+                                            choice; clear => a probe that does not match here is a definite miss (no second fetch) */
 
 struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 9..16 bytes, exact 128-bit key */
     uint32_t k[4];                       /* piece bytes little-endian, zero padded */

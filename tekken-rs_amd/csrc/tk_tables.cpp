@@ -178,6 +178,22 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
             out.key_mask = (cap16_0 << grow) - 1;
             done = place(e8, mode, cap8_0 << grow, t8) && place(e16, mode, cap16_0 << grow, out.key_tab);
         }
+        // spill flags: slot s is flagged iff a key whose first choice is s was placed in its second choice
+        auto flag = [&](std::vector<tk_key_entry>& tab, uint32_t mask) {
+            std::vector<uint32_t> spill;
+            for (uint32_t sl = 0; sl <= mask; ++sl) {
+                const tk_key_entry& e = tab[sl];
+                if (e.len == 0) continue;
+                const uint32_t s1 = tk_key_hash(out.key_hash_mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len) & mask;
+                if (s1 != sl) { spill.push_back(s1); ++out.n_key_second; }
+            }
+            for (uint32_t s1 : spill) {
+                if (!(tab[s1].len & TK_KEY_SPILL)) ++out.n_key_spill_slots;
+                tab[s1].len |= TK_KEY_SPILL;
+            }
+        };
+        flag(t8, out.key8_mask);
+        flag(out.key_tab, out.key_mask);
         out.key8_tab.resize(t8.size());
         for (size_t i = 0; i < t8.size(); ++i) out.key8_tab[i] = tk_key8_entry{{t8[i].k[0], t8[i].k[1]}, t8[i].rank, t8[i].len};
     }

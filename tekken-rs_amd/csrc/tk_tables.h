@@ -42,7 +42,7 @@ struct TkHostTables {
     uint32_t key8_mask = 0, key_mask = 0, long_mask = 0, pair_mask = 0, key_hash_mode = 0;
     uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
     uint32_t p1inv = 0, p2inv = 0;
-    uint64_t n_pairs = 0, n_key = 0, n_long = 0;
+    uint64_t n_pairs = 0, n_key = 0, n_long = 0, n_key_second = 0, n_key_spill_slots = 0;
 
     TkTablesView host_view() const;
 };

@@ -103,7 +103,21 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
             const uint64_t base = cursor, end = cursor + span, g0 = base & ~3ull;
             if (end - g0 <= TKD_IMG_BYTES) {
                 const uint32_t off = (uint32_t)(dst - g0);
-                for (uint32_t k = 0; k < len; ++k) img8[off + k] = src[k];
+                if (len <= 16u) {
+                    // one 16-byte load of the token bytes (the blobs carry >= 16 bytes of slack), then byte stores into
+                    // the LDS image from registers: a per-byte global gather costs the L1 a lane per clock and byte
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    if (len) {
+                        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_u;
+                        const u32x4_u v = *reinterpret_cast<const u32x4_u*>(src);
+                        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k)
+                        if (k < len) img8[off + k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+                } else {
+                    for (uint32_t k = 0; k < len; ++k) img8[off + k] = src[k];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

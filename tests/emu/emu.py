@@ -22,6 +22,8 @@ def lib():
                                        u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p,
                                        u64p, u8p, u64p, u64p]
         L.emu_last_error.restype = ctypes.c_char_p
+        L.emu_table_info.restype = ctypes.c_int
+        L.emu_table_info.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, u64p]
         L.emu_flat_encode_batch.restype = ctypes.c_int
         L.emu_flat_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                             u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, u64p, u8p, u8p,
@@ -94,3 +96,16 @@ def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, ad
         a, b = int(offs[d]), int(offs[d + 1])
         starts.append([i for i in range(b - a) if dbg[a + i]])
     return ids, starts, [d for d in range(D) if fl[d]]
+
+
+def table_info(token_bytes, num_special):
+    """Facts about the device tables the host builder makes for this vocabulary."""
+    toffs = np.zeros(len(token_bytes) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
+    out = np.zeros(6, np.uint64)
+    rc = lib().emu_table_info(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special, _p(out, ctypes.c_uint64))
+    if rc != 0:
+        raise RuntimeError("emu_table_info rc=%d: %s" % (rc, lib().emu_last_error().decode()))
+    return dict(key_hash_mode=int(out[0]), key8_slots=int(out[1]), key16_slots=int(out[2]), keys_in_second_slot=int(out[3]),
+                flagged_slots=int(out[4]), pair_buckets=int(out[5]))

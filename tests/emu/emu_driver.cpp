@@ -225,3 +225,13 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     out_offs[n_docs] = t;
     return TK_OK;
 }
+
+// table facts for tests: out = {key_hash_mode, KEY8 slots, KEY16 slots, keys stored in their second slot, flagged slots, PAIR buckets}
+extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint64_t* out) {
+    TkHostTables T;
+    int rc = tk_build_tables(blob, offs, n_ranks, num_special, 1, 2, T, g_err);
+    if (rc != TK_OK) return rc;
+    out[0] = T.key_hash_mode; out[1] = (uint64_t)T.key8_mask + 1; out[2] = (uint64_t)T.key_mask + 1;
+    out[3] = T.n_key_second; out[4] = T.n_key_spill_slots; out[5] = (uint64_t)T.pair_mask + 1;
+    return TK_OK;
+}

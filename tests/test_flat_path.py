@@ -150,3 +150,31 @@ def test_emu_flat_utf8(test_vocab):
             for _ in range(150)]
     _emu_check(test_vocab, docs)
     _emu_check(test_vocab, ["x'\u017f y'\u017fz '\u017f".encode(), ("\uff11" * 300).encode(), ("\u4e2d\u6587" * 10 + " ").encode() * 30])
+
+
+def test_key_hash_fallback_mode(test_vocab):
+    """Three 12-byte tokens built to have the SAME cheap key hash (mode 0 folds the upper 8 bytes into the lower ones):
+    a cuckoo slot pair cannot hold three keys, so the table builder has to fall back to the strong hash (mode 1) --
+    and the lookups must still be exact, for these tokens and for everything else."""
+    import struct
+
+    def rotl(x, r):
+        return ((x << r) | (x >> (32 - r))) & 0xFFFFFFFF
+    x, k1 = 0x6C6C6568, 0x6F77206F                       # "hell", "o wo"
+    extra = []
+    for k2 in (0x61616161, 0x62626262, 0x63636363):      # "aaaa", "bbbb", "cccc"
+        extra.append(struct.pack("<III", x ^ rotl(k2, 13), k1, k2))
+    assert len(set(extra)) == 3
+    toks = list(test_vocab["tokens"]) + [t for t in extra if t not in test_vocab["tokens"]]
+    v = dict(test_vocab, tokens=toks)
+    assert emu.table_info(test_vocab["tokens"], test_vocab["num_special"])["key_hash_mode"] == 0
+    info = emu.table_info(toks, v["num_special"])
+    assert info["key_hash_mode"] == 1 and info["flagged_slots"] <= info["keys_in_second_slot"]
+    docs = [b"hello world aaaa", b"plain text stays exact 123", extra[0] + b" " + extra[1], extra[2]]
+    _emu_check(v, docs, check_split=False)
+    o = helpers.oracle_for(v)
+    base = len(test_vocab["tokens"])
+    # a piece that IS one of the colliding tokens comes back as that single token (whole-piece lookup, not a merge)
+    got, _, _ = emu.flat_encode_batch(v["tokens"], v["num_special"], v["bos"], v["eos"], [b"x" + extra[0][1:]], False, False)
+    assert got[0] == o.encode(b"x" + extra[0][1:], False, False)
+    assert base + 0 < len(toks)

@@ -57,7 +57,7 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
-    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_holes, f_info;  // flat path (tk_flat.hip)
+    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_holes, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
@@ -171,7 +171,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
-                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_holes, &c->f_info};
+                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_holes, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -295,6 +295,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, c->f_mcnt.reserve((5 * n_chunks + 1) * 4));   // 4 C miss counts (class-major) | C slot counts (one scan)
     TK_HIP(c, c->f_mpfx.reserve((5 * n_chunks + 2) * 8));
     TK_HIP(c, c->f_info.reserve((n_docs + 1) * 16));
+    TK_HIP(c, c->f_wfirst.reserve((n_chunks * (TKF_MISSOFF2 / 64 + 1) + 64) * 4));   // one entry per 64 queued pieces of 2..16 bytes
     TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
     const uint64_t scan_n = n_docs > 5 * n_chunks ? n_docs : 5 * n_chunks;
@@ -316,6 +317,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.miss_count = (uint32_t*)c->f_mcnt.p;
     fa.miss_prefix = (const uint64_t*)c->f_mpfx.p;
     fa.holes = (uint32_t*)c->f_flags.p + (n_docs + 1);
+    fa.wave_first = (uint32_t*)c->f_wfirst.p;
     fa.t = c->dview;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
 

@@ -50,6 +50,16 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
     for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
+// wave w of tk_merge_kernel starts with item 64 w: note down which sub-queue holds it (thread e owns the waves whose
+// first item falls into sub-queue e), so that the merge waves do not have to search the prefix sums
+__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uint64_t* __restrict__ prefix, uint64_t n_e,
+                                                                        uint32_t* __restrict__ wave_first) {
+    const uint64_t e = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
+    if (e >= n_e) return;
+    const uint64_t lo = prefix[e], hi = prefix[e + 1];
+    for (uint64_t w = (lo + 63) / 64; w * 64 < hi; ++w) wave_first[w] = (uint32_t)e;
+}
+
 // persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are)
 __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
@@ -301,6 +311,8 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     uint64_t b1 = (a.n_chunks * 4 + 3) / 4, b2 = (a.n_chunks + 3) / 4;
     if (b1 > cap) b1 = cap;
     if (b2 > cap / 2) b2 = cap / 2;
+    hipLaunchKernelGGL(tk_merge_wavefirst_kernel, dim3(tkf_blocks(2 * a.n_chunks)), dim3(TKF_BLOCK), 0, s, a.miss_prefix,
+                       2 * a.n_chunks, a.wave_first);
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKF_BLOCK), 0, s, a);
     hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();

@@ -588,31 +588,66 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
     const uint64_t first = WIDE ? prefix[2 * a.n_chunks] : 0, total = WIDE ? prefix[n_e] : prefix[2 * a.n_chunks];
     const uint64_t item0 = first + wave_id * 64;
     if (item0 >= total) return;                       // wave-uniform
-    // sub-queue of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
-    uint64_t lo = 0, hi = n_e;                        // invariant: prefix[lo] <= item0 < prefix[hi]
-    while (hi - lo > 1) {
-        const uint64_t step = (hi - lo + 63) / 64;
-        const uint64_t q = lo + (uint64_t)lane * step;
-        const bool le = q < hi && prefix[q] <= item0;
-        const uint64_t LE = wv_ballot(le);            // a prefix of the lanes (lane 0 always)
-        const int top = tk_msb64(LE);
-        const uint64_t nlo = lo + (uint64_t)top * step;
-        const uint64_t nhi = nlo + step < hi ? nlo + step : hi;
-        lo = nlo;
-        hi = nhi;
-    }
-    // every lane: the sub-queue of its own item, searched from the wave's first one on
     const uint64_t item = item0 + (uint64_t)lane;
     const bool have = item < total;
-    uint64_t cl = lo, ch = lo + 64 < n_e ? lo + 64 : n_e;   // prefix[cl] <= item < prefix[ch]
-    if (have) {
-        while (prefix[ch] <= item) {                  // never past n_e: prefix[n_e] >= total > item
-            cl = ch;
-            ch = ch + 64 < n_e ? ch + 64 : n_e;
+    uint64_t cl = 0, pcl = 0;                         // the lane's sub-queue and its first item
+    if (!WIDE) {
+        // the wave's first sub-queue was written down by tk_merge_wavefirst_kernel; the sub-queues of the 64 items
+        // follow from ONE coalesced load of the next 64 prefix sums and a binary search across the lanes (bpermute)
+        uint64_t base = a.wave_first[wave_id];        // prefix[base] <= item0
+        uint64_t pbase = prefix[base];
+        bool done = !have;
+        for (;;) {
+            const uint64_t idx = base + 1 + (uint64_t)lane;
+            const uint64_t pf = idx <= n_e ? prefix[idx] : ~0ull;
+            // d = first item of sub-queue idx relative to item0, clamped to 0..65 (non-decreasing over the lanes)
+            const uint32_t d = pf <= item0 ? 0u : (pf - item0 > 64 ? 65u : (uint32_t)(pf - item0));
+            // cnt = number of lanes j with d_j <= lane: binary lifting over the lanes (bpermute), then the 64th
+            uint32_t cnt = 0;
+            for (uint32_t step = 32; step >= 1; step >>= 1) {
+                const uint32_t dm = wv_shfl(d, (int)(cnt + step - 1u));
+                if (dm <= (uint32_t)lane) cnt += step;
+            }
+            const uint32_t d63 = wv_shfl(d, 63);
+            if (cnt == 63u && d63 <= (uint32_t)lane) cnt = 64u;
+            const uint32_t dprev = wv_shfl(d, cnt ? (int)cnt - 1 : 0);
+            if (!done && cnt < 64u) {
+                cl = base + cnt;
+                pcl = cnt ? item0 + dprev : pbase;       // (d is exact for every entry <= item0 + 63)
+                done = true;
+            }
+            if (wv_ballot(!done) == 0ull) break;
+            // all 64 sub-queues start at or below some lane's item (sparse queues): go on with the next 64
+            pbase = ((uint64_t)wv_shfl((uint32_t)(pf >> 32), 63) << 32) | wv_shfl((uint32_t)pf, 63);
+            base += 64;
         }
-        while (ch - cl > 1) {
-            const uint64_t mid = (cl + ch) / 2;
-            if (prefix[mid] <= item) cl = mid; else ch = mid;
+    } else {
+        // sub-queue of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
+        uint64_t lo = 0, hi = n_e;                        // invariant: prefix[lo] <= item0 < prefix[hi]
+        while (hi - lo > 1) {
+            const uint64_t step = (hi - lo + 63) / 64;
+            const uint64_t q = lo + (uint64_t)lane * step;
+            const bool le = q < hi && prefix[q] <= item0;
+            const uint64_t LE = wv_ballot(le);            // a prefix of the lanes (lane 0 always)
+            const int top = tk_msb64(LE);
+            const uint64_t nlo = lo + (uint64_t)top * step;
+            const uint64_t nhi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+        // every lane: the sub-queue of its own item, searched from the wave's first one on
+        uint64_t ch = lo + 64 < n_e ? lo + 64 : n_e;      // prefix[cl] <= item < prefix[ch]
+        cl = lo;
+        if (have) {
+            while (prefix[ch] <= item) {                  // never past n_e: prefix[n_e] >= total > item
+                cl = ch;
+                ch = ch + 64 < n_e ? ch + 64 : n_e;
+            }
+            while (ch - cl > 1) {
+                const uint64_t mid = (cl + ch) / 2;
+                if (prefix[mid] <= item) cl = mid; else ch = mid;
+            }
+            pcl = prefix[cl];
         }
     }
     uint32_t rec = 0;
@@ -621,7 +656,7 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
         const uint64_t k = cl / a.n_chunks;
         chunk = cl - k * a.n_chunks;
         const uint32_t off = k == 0 ? TKF_MISSOFF0 : k == 1 ? TKF_MISSOFF1 : k == 2 ? TKF_MISSOFF2 : TKF_MISSOFF3;
-        rec = a.miss_list[chunk * TKF_MISSCAP + off + (item - prefix[cl])];
+        rec = a.miss_list[chunk * TKF_MISSCAP + off + (item - pcl)];
     }
     tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane);
 }

@@ -137,6 +137,10 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         for (uint64_t e = 0; e < 4 * n_chunks; ++e) mpfx[e + 1] = mpfx[e] + miss_count[e];
         fa.miss_prefix = mpfx.data();
         const uint64_t n_narrow = mpfx[2 * n_chunks], n_wide = mpfx[4 * n_chunks] - n_narrow;
+        std::vector<uint32_t> wave_first(n_narrow / 64 + 2, 0);
+        for (uint64_t e = 0; e < 2 * n_chunks; ++e)
+            for (uint64_t w = (mpfx[e] + 63) / 64; w * 64 < mpfx[e + 1]; ++w) wave_first[w] = (uint32_t)e;
+        fa.wave_first = wave_first.data();
         for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
             tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane); });
             ops += tkemu::g_wave->n_ops;

@@ -49,25 +49,29 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None):
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = [s.tolist() for s in all_sizes]
     if rank == dst:
-        ids_parts = [None] * world
-        cnt_parts = [None] * world
+        # one output buffer, every peer's transfer lands in its slice (no concatenation pass over the gathered ids)
+        n_ids = [s[0] for s in all_sizes]
+        n_cnt = [s[1] for s in all_sizes]
+        ids = torch.empty(sum(n_ids), dtype=local_ids.dtype, device=dev)
+        counts = torch.empty(sum(n_cnt), dtype=torch.int64, device=dev)
         ops = []
+        i0 = c0 = 0
         for r in range(world):
+            ids_r, cnt_r = ids[i0:i0 + n_ids[r]], counts[c0:c0 + n_cnt[r]]
+            i0 += n_ids[r]
+            c0 += n_cnt[r]
             if r == dst:
-                ids_parts[r], cnt_parts[r] = local_ids, local_doc_counts
+                ids_r.copy_(local_ids)
+                cnt_r.copy_(local_doc_counts)
                 continue
-            ids_parts[r] = torch.empty(all_sizes[r][0], dtype=local_ids.dtype, device=dev)
-            cnt_parts[r] = torch.empty(all_sizes[r][1], dtype=torch.int64, device=dev)
             peer = dist.get_global_rank(group, r) if group is not None else r
-            if all_sizes[r][0]:
-                ops.append(dist.P2POp(dist.irecv, ids_parts[r], peer, group))
-            if all_sizes[r][1]:
-                ops.append(dist.P2POp(dist.irecv, cnt_parts[r], peer, group))
+            if n_ids[r]:
+                ops.append(dist.P2POp(dist.irecv, ids_r, peer, group))
+            if n_cnt[r]:
+                ops.append(dist.P2POp(dist.irecv, cnt_r, peer, group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        ids = torch.cat(ids_parts) if world > 1 else local_ids
-        counts = torch.cat(cnt_parts) if world > 1 else local_doc_counts
         offs = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=offs[1:])
         return ids, offs

@@ -178,3 +178,22 @@ def test_key_hash_fallback_mode(test_vocab):
     got, _, _ = emu.flat_encode_batch(v["tokens"], v["num_special"], v["bos"], v["eos"], [b"x" + extra[0][1:]], False, False)
     assert got[0] == o.encode(b"x" + extra[0][1:], False, False)
     assert base + 0 < len(toks)
+
+
+def _boundary_docs(pads, lens):
+    """runs of every class placed so that they start / end around the region geometry (32-byte left halo, 928 committed,
+    64-byte right halo, 64-byte piece limit)"""
+    docs = []
+    for pad in pads:
+        for ch in ("1", "\n", " ", "a", "!", "中", "１"):
+            for rl in lens:
+                docs.append(("x y " * (pad // 4) + "q" * (pad % 4) + ch * rl + " z").encode())
+    return docs
+
+
+def test_emu_flat_region_geometry(small_vocab):
+    docs = _boundary_docs((864, 896, 927, 928, 960), (31, 32, 33, 64, 65))
+    flagged = _emu_check(small_vocab, docs, False, False, check_split=True)
+    assert 0 < len(flagged) < len(docs)
+    # total length a multiple of the commit size, documents ending exactly on chunk / region boundaries
+    _emu_check(small_vocab, [b"ab " * 309 + b"c", b"d" * 32, b"e f" * 298 + b"gh", b"", b"i" * 928, b"j k " * 232], True, True)

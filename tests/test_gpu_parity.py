@@ -151,6 +151,11 @@ def test_flat_path_stress(eng_small, test_vocab):
     docs += ["".join(rng.choice(ualpha) * rng.choice([1, 1, 1, 2, 3, 7, 20]) for _ in range(rng.randint(0, 60))).encode()
              for _ in range(1500)]
     docs += helpers.random_unicode_docs(1500, seed=12, max_len=300)
+    # runs of every class that start / end around the region geometry (halos, commit size, piece limit), every phase
+    for pad in list(range(860, 1000, 3)):
+        for ch in ("1", "\n", " ", "a", "!", "\u4e2d", "\uff11"):
+            for rl in (31, 32, 33, 63, 64, 65):
+                docs.append(("x y " * (pad // 4) + "q" * (pad % 4) + ch * rl + " z").encode())
     rng.shuffle(docs)
     data = np.frombuffer(b"".join(docs), dtype=np.uint8)
     offs = np.zeros(len(docs) + 1, np.uint64)

@@ -47,17 +47,17 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
     TkPolyPow pw;
     pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
     tk_flat_init_lds(lds, lane);
+    uint64_t c_begin = wave, c_end = a.n_chunks, c_step = n_waves;
     if (gridDim.x >= 8) {
         // XCD-aware: blocks b and b + 8 share an XCD (and its L2), so the blocks of one residue class take ONE contiguous
         // eighth of the chunks -- neighbouring chunks share their halo bytes and the cache lines of the per-chunk /
         // per-document arrays they read and write.  (Placement is a speed matter only.)
         const uint64_t label = blockIdx.x & 7u, nb = (gridDim.x - label + 7u) / 8u;
-        const uint64_t lo = a.n_chunks * label / 8, hi = a.n_chunks * (label + 1) / 8;
-        const uint64_t lw = (uint64_t)(blockIdx.x >> 3) * (TKF_BLOCK / 64) + (threadIdx.x >> 6), nlw = nb * (TKF_BLOCK / 64);
-        for (uint64_t c = lo + lw; c < hi; c += nlw) tk_flat_chunk(a, c, lane, lds, pw);
-    } else {
-        for (uint64_t c = wave; c < a.n_chunks; c += n_waves) tk_flat_chunk(a, c, lane, lds, pw);
+        c_begin = a.n_chunks * label / 8 + (uint64_t)(blockIdx.x >> 3) * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
+        c_end = a.n_chunks * (label + 1) / 8;
+        c_step = nb * (TKF_BLOCK / 64);
     }
+    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk(a, c, lane, lds, pw);
 }
 
 // wave w of tk_merge_kernel starts with item 64 w: note down which sub-queue holds it (thread e owns the waves whose

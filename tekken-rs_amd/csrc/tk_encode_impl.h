@@ -126,44 +126,53 @@ TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, u
 
 struct alignas(16) tk_u64x2 { uint64_t x, y; };
 
-// PAIR: two buckets of two entries, fetched together (one 16-byte load each); an empty entry is all ones and
-// matches no key (ids are < 2^21)
+// PAIR: buckets of two entries (one 16-byte load).  Most probes of the merge loop are for pairs that are NOT tokens;
+// the first-choice bucket alone settles them unless it is flagged (something spilled from it): one scattered load per
+// probe instead of two -- the merge kernel is bound by exactly those loads.  An empty entry is all ones and matches
+// no key.
+TK_DEV uint32_t tk_pair_in(const tk_u64x2& p, uint64_t key) {
+    uint32_t r = TK_RANK_MAX;
+    if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
+    if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
+    return r;
+}
+TK_DEV bool tk_pair_spilled(const tk_u64x2& p) { return p.x != TK_PAIR_EMPTY && (p.x & TK_PAIR_SPILL) != 0ull; }
+
 TK_DEV uint32_t tk_probe_pair(const TkTablesView& t, uint32_t a, uint32_t b) {
     const uint64_t key = ((uint64_t)a << TK_ID_BITS) | (uint64_t)b;
     const uint32_t h = tk_pair_hash(a, b);
     tk_u64x2 p = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h & t.pair_mask));
-    tk_u64x2 q = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h) & t.pair_mask));
-    WV_PIN(p.x); WV_PIN(p.y); WV_PIN(q.x); WV_PIN(q.y);   // both buckets in flight before any compare
-    uint32_t r = TK_RANK_MAX;
-    if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
-    if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
-    if (tk_pair_key(q.x) == key) r = tk_pair_rank(q.x);
-    if (tk_pair_key(q.y) == key) r = tk_pair_rank(q.y);
+    WV_PIN(p.x); WV_PIN(p.y);
+    uint32_t r = tk_pair_in(p, key);
+    if (r == TK_RANK_MAX && tk_pair_spilled(p)) {
+        tk_u64x2 q = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h) & t.pair_mask));
+        WV_PIN(q.x); WV_PIN(q.y);
+        r = tk_pair_in(q, key);
+    }
     return r;
 }
 
-TK_DEV uint32_t tk_pair_match(const tk_u64x2& p, const tk_u64x2& q, uint64_t key) {
-    uint32_t r = TK_RANK_MAX;
-    if (tk_pair_key(p.x) == key) r = tk_pair_rank(p.x);
-    if (tk_pair_key(p.y) == key) r = tk_pair_rank(p.y);
-    if (tk_pair_key(q.x) == key) r = tk_pair_rank(q.x);
-    if (tk_pair_key(q.y) == key) r = tk_pair_rank(q.y);
-    return r;
-}
-
-// two independent PAIR probes: all four bucket loads are in flight together
+// two independent PAIR probes: both first-choice buckets are in flight together, and so are the second-choice ones of
+// the (few) lanes that need them
 TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t& r0,
                              uint32_t& r1) {
     const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
     const uint32_t h0 = tk_pair_hash(a0, b0), h1 = tk_pair_hash(a1, b1);
     tk_u64x2 p0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h0 & t.pair_mask));
-    tk_u64x2 q0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h0) & t.pair_mask));
     tk_u64x2 p1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h1 & t.pair_mask));
-    tk_u64x2 q1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h1) & t.pair_mask));
-    WV_PIN(p0.x); WV_PIN(p0.y); WV_PIN(q0.x); WV_PIN(q0.y);
-    WV_PIN(p1.x); WV_PIN(p1.y); WV_PIN(q1.x); WV_PIN(q1.y);
-    r0 = tk_pair_match(p0, q0, key0);
-    r1 = tk_pair_match(p1, q1, key1);
+    WV_PIN(p0.x); WV_PIN(p0.y); WV_PIN(p1.x); WV_PIN(p1.y);
+    r0 = tk_pair_in(p0, key0);
+    r1 = tk_pair_in(p1, key1);
+    const bool n0 = r0 == TK_RANK_MAX && tk_pair_spilled(p0), n1 = r1 == TK_RANK_MAX && tk_pair_spilled(p1);
+    if (n0 || n1) {
+        tk_u64x2 q0, q1;
+        q0.x = q0.y = q1.x = q1.y = TK_PAIR_EMPTY;
+        if (n0) q0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h0) & t.pair_mask));
+        if (n1) q1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h1) & t.pair_mask));
+        WV_PIN(q0.x); WV_PIN(q0.y); WV_PIN(q1.x); WV_PIN(q1.y);
+        if (n0) r0 = tk_pair_in(q0, key0);
+        if (n1) r1 = tk_pair_in(q1, key1);
+    }
 }
 
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {

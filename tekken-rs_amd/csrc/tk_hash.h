@@ -96,7 +96,10 @@ TK_HD uint32_t tk_hash_alt(uint32_t h) { return (h << 16) | (h >> 16); }  /* sec
 TK_HD uint64_t tk_pair_pack(uint32_t a, uint32_t b, uint32_t rank) {
     return ((uint64_t)a << (2 * TK_ID_BITS)) | ((uint64_t)b << TK_ID_BITS) | (uint64_t)rank;
 }
-TK_HD uint64_t tk_pair_key(uint64_t e) { return e >> TK_ID_BITS; }
+#define TK_PAIR_SPILL 0x8000000000000000ull  /* in the FIRST entry of a PAIR bucket: some pair whose first choice is this bucket lives
+                                                 in its second one; clear => a probe that does not match here is a definite miss */
+TK_HD uint64_t tk_pair_key(uint64_t e) { return (e >> TK_ID_BITS) & ((1ull << (2 * TK_ID_BITS)) - 1ull); }  /* an EMPTY entry reads
+                                                 as the pair (2^21 - 1, 2^21 - 1): ids are < 2^21 - 1, it matches nothing */
 TK_HD uint32_t tk_pair_rank(uint64_t e) { return (uint32_t)(e & ((1u << TK_ID_BITS) - 1u)); }
 
 #endif

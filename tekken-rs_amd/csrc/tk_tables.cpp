@@ -248,5 +248,19 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         if (ok) break;
         if (nb >= (1u << 30)) { err = "could not place the vocabulary in the PAIR table"; return TK_ERR_INVALID_CONFIG; }
     }
+    // spill flags: bucket b is flagged (bit 63 of its first entry) iff a pair whose first choice is b was placed in its
+    // second choice -- only then can a probe that does not match in b find its pair elsewhere
+    {
+        std::vector<uint64_t> spill;
+        for (uint64_t sl = 0; sl < out.pair_tab.size(); ++sl) {
+            const uint64_t e = out.pair_tab[sl];
+            if (e == TK_PAIR_EMPTY) continue;
+            const uint64_t key = tk_pair_key(e);
+            const uint32_t ida = (uint32_t)(key >> TK_ID_BITS), idb = (uint32_t)(key & ((1u << TK_ID_BITS) - 1u));
+            const uint64_t b1 = tk_pair_hash(ida, idb) & out.pair_mask;
+            if (b1 != sl / 2) spill.push_back(b1);
+        }
+        for (uint64_t b1 : spill) out.pair_tab[2 * b1] |= TK_PAIR_SPILL;   // (a bucket that spilled is full: its first entry is real)
+    }
     return TK_OK;
 }

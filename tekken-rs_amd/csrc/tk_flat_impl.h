@@ -44,9 +44,11 @@
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
 #define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
-#define TKF_L_CL (TKF_L_BPFX + 64)                  /* [3 * 64] classes L, N, S of the multi-byte code points */
-#define TKF_L_KM (TKF_L_CL + 3 * 64)                 /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
-#define TKF_LDS_WORDS (TKF_L_KM + 17 * 4)
+#define TKF_L_CL TKF_L_LIST                          /* [3 * 64] classes L, N, S of the multi-byte code points (step 1 only: shares the
+                                                        words of the piece list, which is built in step 5) */
+#define TKF_L_KM (TKF_L_BPFX + 64)                  /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
+#define TKF_L_TXT (TKF_L_KM + 17 * 4)                /* [256 + 4] the region's bytes: a piece's 16 bytes are read from here */
+#define TKF_LDS_WORDS (TKF_L_TXT + 256 + 4)
 
 
 // ------------------------------------------------------------------------------------------
@@ -281,6 +283,11 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
     }
+    {
+        uint32_t* txt = lds + TKF_L_TXT + 4 * lane;   // bytes outside [0, n) are zero
+        txt[0] = x[0]; txt[1] = x[1]; txt[2] = x[2]; txt[3] = x[3];
+        if (lane == 0) { lds[TKF_L_TXT + 256] = 0u; lds[TKF_L_TXT + 257] = 0u; lds[TKF_L_TXT + 258] = 0u; lds[TKF_L_TXT + 259] = 0u; }
+    }
     TkfClass m = tkf_classify(x);
     if (tkf_any(m.HI)) {
         // multi-byte code points: every lane walks the lead bytes among its 16 bytes, decodes the code point, looks its
@@ -453,14 +460,15 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             if (len > 64u) {
                 toolong = true;
             } else if (len <= 16u) {
-                // the piece's first 16 bytes (a single byte takes its rank from here too)
-                uint32_t kk[4] = {0u, 0u, 0u, 0u};
-                const int64_t g = r0 + (int64_t)pos;
-                if (g + 16 <= n) {
-                    wv_load16(a.bytes + g, kk);
-                } else {
-                    for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)rbytes[pos + q] << (8 * (q & 3));
-                }
+                // the piece's first 16 bytes from the LDS copy of the region (five aligned dwords, funnel-shifted; a single
+                // byte takes its rank from here too): a scattered 16-byte global load per lane is what this kernel can
+                // least afford
+                const uint32_t* tw = lds + TKF_L_TXT + (pos >> 2);
+                const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4];
+                const uint32_t sh = pos & 3u;
+                uint32_t kk[4];
+                kk[0] = wv_alignbyte(t1, t0, sh); kk[1] = wv_alignbyte(t2, t1, sh);
+                kk[2] = wv_alignbyte(t3, t2, sh); kk[3] = wv_alignbyte(t4, t3, sh);
                 // zero the bytes past the piece (masks by length from LDS)
                 const uint32_t* km = lds + TKF_L_KM + 4u * len;
                 kk[0] &= km[0]; kk[1] &= km[1]; kk[2] &= km[2]; kk[3] &= km[3];

@@ -81,7 +81,8 @@ int tk_encode_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offse
 void tk_free_result(tk_result* r);
 
 /* Same computation with inputs already resident in HBM (hipMalloc'ed on the context's device):
- * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64.  Work is enqueued on
+ * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64 (non-decreasing, [0] = 0, [n_docs] = n_bytes:
+ * not checked on this entry).  Work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = HIP's null stream, so the work is ordered after whatever the
  * caller already enqueued there) and the call returns after the stream has drained.  *d_ids / *d_out_offsets are device buffers owned by the context, valid
  * until the next call on it; *n_ids = total ids. */

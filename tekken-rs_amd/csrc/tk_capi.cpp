@@ -57,7 +57,7 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
-    DevBuf f_first, f_tmp, f_k, f_P, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_holes, f_info;  // flat path (tk_flat.hip)
+    DevBuf f_first, f_tmp, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
@@ -171,7 +171,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
-                      &c->f_first, &c->f_tmp, &c->f_k, &c->f_P, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_holes, &c->f_info};
+                      &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -44,8 +44,6 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
     uint32_t* lds = lds_all + (threadIdx.x >> 6) * TKF_LDS_WORDS;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
-    TkPolyPow pw;
-    pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
     tk_flat_init_lds(lds, lane);
     uint64_t c_begin = wave, c_end = a.n_chunks, c_step = n_waves;
     if (gridDim.x >= 8) {
@@ -57,7 +55,7 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
         c_end = a.n_chunks * (label + 1) / 8;
         c_step = nb * (TKF_BLOCK / 64);
     }
-    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk(a, c, lane, lds, pw);
+    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk(a, c, lane, lds);
 }
 
 // wave w of tk_merge_kernel starts with item 64 w: note down which sub-queue holds it (thread e owns the waves whose

@@ -10,7 +10,8 @@
 //   * document boundaries are a mask (DS): look-behind shifts are cut at a document start, look-ahead
 //     shifts at a document end, runs are broken there -- documents never cost a branch;
 //   * piece starts are enumerated into LDS and probed ONE LANE PER PIECE (64 probes per instruction
-//     instead of ~13 with one lane per byte);
+//     instead of ~13 with one lane per byte); the piece bytes come from an LDS copy of the region, the
+//     probe is one scattered load for most pieces (KEY8: 16-byte entries; spill flags, tk_hash.h);
 //   * a piece that misses the vocabulary reserves `len` id slots and is queued; tk_merge_wave merges the
 //     queue ONE LANE PER PIECE (tiktoken's order) -- 64 independent chains of dependent
 //     PAIR probes per wave at high occupancy -- and marks the slots it does not need as holes;
@@ -261,8 +262,7 @@ TK_DEV void tk_flat_init_lds(uint32_t* lds, int lane) {
 
 TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
-TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds, const TkPolyPow& pw) {
-    (void)pw;
+TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
     const int64_t n = (int64_t)a.n_bytes;
     const int64_t c0 = (int64_t)c * TKF_COMMIT, r0 = c0 - TKF_HL, r1 = r0 + TKF_REGION;

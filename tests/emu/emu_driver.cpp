@@ -127,10 +127,8 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     uint64_t ops = 0;
     if (n_chunks) {
         tkemu::run_wave([&](int lane) {
-            TkPolyPow pw;
-            pw.pw1 = pw.ipw1 = pw.pw2 = pw.ipw2 = 1u;
             tk_flat_init_lds(lds.data(), lane);
-            for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data(), pw);
+            for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data());
         });
         ops += tkemu::g_wave->n_ops;
         std::vector<uint64_t> mpfx(4 * n_chunks + 1, 0);

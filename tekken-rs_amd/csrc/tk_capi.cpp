@@ -55,7 +55,7 @@ struct tk_ctx {
     TkTablesView dview;
     DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
     bool have_specials = false;
-    DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs;
+    DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     DevBuf f_first, f_tmp, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
@@ -168,7 +168,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
-                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs,
+                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
@@ -588,6 +588,7 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     TK_HIP(c, c->dec_lens.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->dec_offs.reserve((n_docs + 1) * 8));
     TK_HIP(c, c->dec_err.reserve(64));
+    TK_HIP(c, c->dec_hi.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->block_sums.reserve((n_docs / 2048 + 4) * 8));
     TkDecodeArgs a;
     memset(&a, 0, sizeof(a));
@@ -598,6 +599,7 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.lens = (uint32_t*)c->dec_lens.p;
     a.out_offs = (uint64_t*)c->dec_offs.p;
     a.err = (unsigned long long*)c->dec_err.p;
+    a.doc_hi = (uint32_t*)c->dec_hi.p;
     a.tok_blob = (const uint8_t*)c->t_blob.p;
     a.tok_offs = (const uint32_t*)c->t_offs.p;
     a.sp_blob = (const uint8_t*)c->t_spblob.p;

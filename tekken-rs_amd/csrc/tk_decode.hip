@@ -81,6 +81,7 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
         const uint64_t i0 = a.id_offs[d], i1 = a.id_offs[d + 1];
         uint64_t cursor = a.out_offs[d];
+        bool hi_any = false;                       // some byte >= 0x80 among the token bytes this lane emitted
         for (uint64_t c0 = i0; c0 < i1; c0 += 64) {
             const uint64_t i = c0 + (uint64_t)lane;
             const uint8_t* src = nullptr;
@@ -114,9 +115,17 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
                     }
 #pragma unroll
                     for (uint32_t k = 0; k < 16u; ++k)
-                        if (k < len) img8[off + k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+                        if (k < len) {
+                            const uint32_t bk = (w[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
+                            img8[off + k] = (uint8_t)bk;
+                            hi_any |= bk >= 0x80u;
+                        }
                 } else {
-                    for (uint32_t k = 0; k < len; ++k) img8[off + k] = src[k];
+                    for (uint32_t k = 0; k < len; ++k) {
+                        const uint8_t bk = src[k];
+                        img8[off + k] = bk;
+                        hi_any |= bk >= 0x80u;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -135,10 +144,16 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
                 __builtin_amdgcn_wave_barrier();
             } else {
                 uint8_t* out = a.out_bytes + dst;  // unusually long tokens: direct byte stores
-                for (uint32_t k = 0; k < len; ++k) out[k] = src[k];
+                for (uint32_t k = 0; k < len; ++k) {
+                    const uint8_t bk = src[k];
+                    out[k] = bk;
+                    hi_any |= bk >= 0x80u;
+                }
             }
             cursor = end;
         }
+        const bool doc_hi = __ballot(hi_any) != 0ull;   // ASCII documents need no UTF-8 validation pass
+        if (lane == 0) a.doc_hi[d] = doc_hi ? 1u : 0u;
     }
 }
 
@@ -154,6 +169,7 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_BLOCK / 64);
     const uint8_t* b = a.out_bytes;
     for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
+        if (a.doc_hi[d] == 0u) continue;            // the emit kernel saw only ASCII bytes: always valid
         const uint64_t s0 = a.out_offs[d], s1 = a.out_offs[d + 1];
         bool err = false;
         for (uint64_t p = s0 + (uint64_t)lane; p < s1; p += 64) {

@@ -47,6 +47,7 @@ struct TkDecodeArgs {
     uint8_t* out_bytes;        // [total bytes]
     uint64_t* out_offs;        // [n_docs + 1] exclusive scan of lens
     uint32_t* run_bits;        // bitmap over output bytes: 1 = a run starts here (hard UTF-8 boundary)
+    uint32_t* doc_hi;          // [n_docs] written by emit: the document's text holds a byte >= 0x80 (only those are validated)
     unsigned long long* err;   // [3] see tk_decode.hip
     const uint8_t* tok_blob;   // token bytes by rank
     const uint32_t* tok_offs;  // [n_ranks + 1]

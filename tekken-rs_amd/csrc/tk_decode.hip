@@ -33,8 +33,11 @@ __device__ __forceinline__ uint32_t tkd_piece(const TkDecodeArgs& a, uint32_t id
     }
     const uint32_t r = id - a.num_special;
     if (r >= a.n_ranks) return 0u;
-    *src = a.tok_blob + a.tok_offs[r];
-    return a.tok_offs[r + 1] - a.tok_offs[r];
+    // offs[r] and offs[r + 1] with ONE 8-byte load (4-byte aligned): scattered loads are what this path pays for
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) u32x2_a4;
+    const u32x2_a4 o = *reinterpret_cast<const u32x2_a4*>(a.tok_offs + r);
+    *src = a.tok_blob + o.x;
+    return o.y - o.x;
 }
 
 __device__ __forceinline__ uint32_t tkd_wave_sum(uint32_t v) {

@@ -89,7 +89,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     *out_ctx = nullptr;
     tk_ctx* c = new tk_ctx();
     std::string err;
-    int rc = tk_build_tables(token_bytes, token_offsets, n_ranks, num_special_tokens, bos_id, eos_id, c->host, err);
+    bool from_cache = false;   // TK_TABLE_CACHE_DIR: derived tables from a side file keyed by the rank table (row f-2)
+    int rc = tk_build_tables_cached(token_bytes, token_offsets, n_ranks, num_special_tokens, bos_id, eos_id, c->host, err, &from_cache);
     if (rc != TK_OK) { g_tls_err = err; delete c; return rc; }
 
     int n_dev = 0;
@@ -120,8 +121,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 
     const TkHostTables& h = c->host;
     if (getenv("TK_DEBUG_LOG"))
-        fprintf(stderr, "[tk] tables: KEY8 %u slots, KEY16 %u slots (hash mode %u, %llu keys, %llu in their second slot, %llu slots flagged), PAIR %u buckets (%llu pairs)\n",
-                h.key8_mask + 1, h.key_mask + 1, h.key_hash_mode, (unsigned long long)h.n_key, (unsigned long long)h.n_key_second,
+        fprintf(stderr, "[tk] tables%s: KEY8 %u slots, KEY16 %u slots (hash mode %u, %llu keys, %llu in their second slot, %llu slots flagged), PAIR %u buckets (%llu pairs)\n",
+                from_cache ? " (from cache)" : "", h.key8_mask + 1, h.key_mask + 1, h.key_hash_mode, (unsigned long long)h.n_key, (unsigned long long)h.n_key_second,
                 (unsigned long long)h.n_key_spill_slots, h.pair_mask + 1, (unsigned long long)h.n_pairs);
     if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
         (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||

@@ -2,6 +2,8 @@
 // See tk_hash.h for the layouts and tk_tables.h for provenance.
 #include "tk_tables.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -263,4 +265,113 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         for (uint64_t b1 : spill) out.pair_tab[2 * b1] |= TK_PAIR_SPILL;   // (a bucket that spilled is full: its first entry is real)
     }
     return TK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// table cache (row f-2)
+// ------------------------------------------------------------------------------------------
+#define TK_CACHE_MAGIC 0x42544B54u /* "TKTB" */
+#define TK_CACHE_VERSION 3u        /* bump whenever a table layout or a hash function changes */
+
+static uint64_t fnv1a64(uint64_t h, const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+
+uint64_t tk_tables_key(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint32_t bos_id,
+                       uint32_t eos_id) {
+    const uint32_t head[8] = {TK_CACHE_MAGIC, TK_CACHE_VERSION, n_ranks, num_special, bos_id, eos_id, TK_UC_STAGE1_LEN, TK_UC_STAGE2_LEN};
+    uint64_t h = fnv1a64(0xCBF29CE484222325ull, head, sizeof(head));
+    h = fnv1a64(h, offs, ((size_t)n_ranks + 1) * sizeof(uint32_t));
+    return fnv1a64(h, blob, offs[n_ranks]);
+}
+
+namespace {
+template <class T>
+bool put_vec(FILE* f, const std::vector<T>& v) {
+    const uint64_t n = v.size();
+    return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T>
+bool get_vec(FILE* f, std::vector<T>& v, uint64_t max_elems) {
+    uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1 || n > max_elems) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+struct CacheHead {
+    uint32_t magic, version;
+    uint64_t key;
+    uint32_t key8_mask, key_mask, long_mask, pair_mask, key_hash_mode, n_ranks, num_special, bos_id, eos_id, p1inv, p2inv, pad;
+    uint64_t n_pairs, n_key, n_long, n_key_second, n_key_spill_slots;
+};
+}  // namespace
+
+bool tk_tables_save(const TkHostTables& t, uint64_t key, const std::string& path) {
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)key & 0xFFFF);
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    CacheHead h;
+    memset(&h, 0, sizeof(h));
+    h.magic = TK_CACHE_MAGIC; h.version = TK_CACHE_VERSION; h.key = key;
+    h.key8_mask = t.key8_mask; h.key_mask = t.key_mask; h.long_mask = t.long_mask; h.pair_mask = t.pair_mask;
+    h.key_hash_mode = t.key_hash_mode; h.n_ranks = t.n_ranks; h.num_special = t.num_special; h.bos_id = t.bos_id; h.eos_id = t.eos_id;
+    h.p1inv = t.p1inv; h.p2inv = t.p2inv;
+    h.n_pairs = t.n_pairs; h.n_key = t.n_key; h.n_long = t.n_long; h.n_key_second = t.n_key_second; h.n_key_spill_slots = t.n_key_spill_slots;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && put_vec(f, t.blob) && put_vec(f, t.offs) && put_vec(f, t.uc_stage1) &&
+              put_vec(f, t.uc_stage2) && put_vec(f, t.key8_tab) && put_vec(f, t.key_tab) && put_vec(f, t.long_tab) &&
+              put_vec(f, t.pair_tab) && put_vec(f, t.pair2);
+    const uint32_t tail = TK_CACHE_MAGIC;   // a truncated file has no tail
+    ok = ok && fwrite(&tail, 4, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());
+    return ok;
+}
+
+bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CacheHead h;
+    TkHostTables x;
+    const uint64_t lim = 1ull << 31;
+    uint32_t tail = 0;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && h.magic == TK_CACHE_MAGIC && h.version == TK_CACHE_VERSION && h.key == key &&
+              get_vec(f, x.blob, lim) && get_vec(f, x.offs, lim) && get_vec(f, x.uc_stage1, lim) && get_vec(f, x.uc_stage2, lim) &&
+              get_vec(f, x.key8_tab, lim) && get_vec(f, x.key_tab, lim) && get_vec(f, x.long_tab, lim) && get_vec(f, x.pair_tab, lim) &&
+              get_vec(f, x.pair2, lim) && fread(&tail, 4, 1, f) == 1 && tail == TK_CACHE_MAGIC;
+    fclose(f);
+    if (!ok) return false;
+    // sizes must agree with the masks the kernels index with
+    if (x.key8_tab.size() != (size_t)h.key8_mask + 1 || x.key_tab.size() != (size_t)h.key_mask + 1 ||
+        x.long_tab.size() != (size_t)h.long_mask + 1 || x.pair_tab.size() != 2 * ((size_t)h.pair_mask + 1) || x.pair2.size() != 65536 ||
+        x.offs.size() != (size_t)h.n_ranks + 1 || x.uc_stage1.size() != TK_UC_STAGE1_LEN || x.uc_stage2.size() != TK_UC_STAGE2_LEN)
+        return false;
+    x.key8_mask = h.key8_mask; x.key_mask = h.key_mask; x.long_mask = h.long_mask; x.pair_mask = h.pair_mask;
+    x.key_hash_mode = h.key_hash_mode; x.n_ranks = h.n_ranks; x.num_special = h.num_special; x.bos_id = h.bos_id; x.eos_id = h.eos_id;
+    x.p1inv = h.p1inv; x.p2inv = h.p2inv;
+    x.n_pairs = h.n_pairs; x.n_key = h.n_key; x.n_long = h.n_long; x.n_key_second = h.n_key_second; x.n_key_spill_slots = h.n_key_spill_slots;
+    t = std::move(x);
+    return true;
+}
+
+int tk_build_tables_cached(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint32_t bos_id,
+                           uint32_t eos_id, TkHostTables& out, std::string& err, bool* from_cache) {
+    if (from_cache) *from_cache = false;
+    const char* dir = getenv("TK_TABLE_CACHE_DIR");
+    if (!dir || !*dir || !blob || !offs || n_ranks < 256) return tk_build_tables(blob, offs, n_ranks, num_special, bos_id, eos_id, out, err);
+    for (uint32_t r = 0; r < n_ranks; ++r)   // (the key walks offs[n_ranks] bytes: the offsets must be sane first)
+        if (offs[r + 1] < offs[r]) return tk_build_tables(blob, offs, n_ranks, num_special, bos_id, eos_id, out, err);
+    const uint64_t key = tk_tables_key(blob, offs, n_ranks, num_special, bos_id, eos_id);
+    char name[64];
+    snprintf(name, sizeof(name), "/tk_tables_%016llx.bin", (unsigned long long)key);
+    const std::string path = std::string(dir) + name;
+    if (tk_tables_load(out, key, path)) {
+        if (from_cache) *from_cache = true;
+        return TK_OK;
+    }
+    const int rc = tk_build_tables(blob, offs, n_ranks, num_special, bos_id, eos_id, out, err);
+    if (rc == TK_OK) (void)tk_tables_save(out, key, path);   // best effort
+    return rc;
 }

@@ -53,4 +53,17 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
 
 uint32_t tk_inverse_u32(uint32_t odd);
 
+// ---- table cache (loader / table-build acceleration, reference src/tekkenizer.rs:222-248,776-816) ----
+// The derived tables depend only on the validated rank table; tk_tables_key hashes exactly the inputs of
+// tk_build_tables (FNV-1a 64 over a format tag, the scalar arguments, the offsets and the token bytes).
+// tk_build_tables_cached: with TK_TABLE_CACHE_DIR set, loads `<dir>/tk_tables_<key>.bin` if it is present and intact,
+// otherwise builds and writes it (atomic rename).  A cache file never changes a result: every field of TkHostTables
+// is stored, the loader checks magic, version, key and sizes and falls back to building on any mismatch.
+uint64_t tk_tables_key(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint32_t bos_id,
+                       uint32_t eos_id);
+bool tk_tables_save(const TkHostTables& t, uint64_t key, const std::string& path);
+bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path);
+int tk_build_tables_cached(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint32_t bos_id,
+                           uint32_t eos_id, TkHostTables& out, std::string& err, bool* from_cache);
+
 #endif

@@ -22,6 +22,8 @@ def lib():
                                        u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p,
                                        u64p, u8p, u64p, u64p]
         L.emu_last_error.restype = ctypes.c_char_p
+        L.emu_table_cache_roundtrip.restype = ctypes.c_int
+        L.emu_table_cache_roundtrip.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         L.emu_table_info.restype = ctypes.c_int
         L.emu_table_info.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, u64p]
         L.emu_flat_encode_batch.restype = ctypes.c_int
@@ -109,3 +111,16 @@ def table_info(token_bytes, num_special):
         raise RuntimeError("emu_table_info rc=%d: %s" % (rc, lib().emu_last_error().decode()))
     return dict(key_hash_mode=int(out[0]), key8_slots=int(out[1]), key16_slots=int(out[2]), keys_in_second_slot=int(out[3]),
                 flagged_slots=int(out[4]), pair_buckets=int(out[5]))
+
+
+def table_cache_roundtrip(token_bytes, num_special, path):
+    """build -> save -> load (a wrong key must be refused) -> compare every field.  Returns timings / file size."""
+    toffs = np.zeros(len(token_bytes) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
+    out = np.zeros(4, np.float64)
+    rc = lib().emu_table_cache_roundtrip(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special,
+                                         os.fsencode(path), _p(out, ctypes.c_double))
+    if rc != 0:
+        raise RuntimeError("emu_table_cache_roundtrip rc=%d: %s" % (rc, lib().emu_last_error().decode()))
+    return dict(build_s=float(out[0]), save_s=float(out[1]), load_s=float(out[2]), file_bytes=int(out[3]))

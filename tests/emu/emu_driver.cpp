@@ -237,3 +237,43 @@ extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_
     out[3] = T.n_key_second; out[4] = T.n_key_spill_slots; out[5] = (uint64_t)T.pair_mask + 1;
     return TK_OK;
 }
+
+// table cache (row f-2): build, save, load, compare field by field; out = {build seconds, save seconds, load seconds, file bytes}
+#include <chrono>
+extern "C" int emu_table_cache_roundtrip(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
+                                         const char* path, double* out) {
+    using clk = std::chrono::steady_clock;
+    TkHostTables A, B;
+    auto t0 = clk::now();
+    int rc = tk_build_tables(blob, offs, n_ranks, num_special, 1, 2, A, g_err);
+    if (rc != TK_OK) return rc;
+    auto t1 = clk::now();
+    const uint64_t key = tk_tables_key(blob, offs, n_ranks, num_special, 1, 2);
+    if (!tk_tables_save(A, key, path)) { g_err = "save failed"; return TK_ERR_RUNTIME; }
+    auto t2 = clk::now();
+    if (tk_tables_load(B, key + 1, path)) { g_err = "a wrong key was accepted"; return TK_ERR_RUNTIME; }
+    auto t3 = clk::now();
+    if (!tk_tables_load(B, key, path)) { g_err = "load failed"; return TK_ERR_RUNTIME; }
+    auto t4 = clk::now();
+    auto same = [](const auto& x, const auto& y) { return x.size() == y.size() && (x.empty() || memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0); };
+    if (!(same(A.blob, B.blob) && same(A.offs, B.offs) && same(A.uc_stage1, B.uc_stage1) && same(A.uc_stage2, B.uc_stage2) &&
+          same(A.key8_tab, B.key8_tab) && same(A.key_tab, B.key_tab) && same(A.long_tab, B.long_tab) && same(A.pair_tab, B.pair_tab) &&
+          same(A.pair2, B.pair2) && A.key8_mask == B.key8_mask && A.key_mask == B.key_mask && A.long_mask == B.long_mask &&
+          A.pair_mask == B.pair_mask && A.key_hash_mode == B.key_hash_mode && A.n_ranks == B.n_ranks && A.num_special == B.num_special &&
+          A.bos_id == B.bos_id && A.eos_id == B.eos_id && A.p1inv == B.p1inv && A.p2inv == B.p2inv && A.n_pairs == B.n_pairs)) {
+        g_err = "loaded tables differ from the built ones";
+        return TK_ERR_RUNTIME;
+    }
+    out[0] = std::chrono::duration<double>(t1 - t0).count();
+    out[1] = std::chrono::duration<double>(t2 - t1).count();
+    out[2] = std::chrono::duration<double>(t4 - t3).count();
+    FILE* f = fopen(path, "rb");
+    out[3] = 0;
+    if (f) { fseek(f, 0, SEEK_END); out[3] = (double)ftell(f); fclose(f); }
+    return TK_OK;
+}
+
+extern "C" int emu_table_cache_load(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, const char* path) {
+    TkHostTables B;
+    return tk_tables_load(B, tk_tables_key(blob, offs, n_ranks, num_special, 1, 2), path) ? TK_OK : TK_ERR_RUNTIME;
+}

@@ -293,3 +293,32 @@ def test_bench_contract_small(tk):
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and "workload" in j["config"]
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["bit_exact_vs_cpu"] is True
     assert j["decode"]["round_trip_exact"] is True
+
+
+def test_table_cache_context(tk, bench_vocab, tmp_path, monkeypatch):
+    """Row f-2: a context created from the table cache (TK_TABLE_CACHE_DIR) encodes exactly like one that built its
+    tables; a damaged cache file is ignored and rewritten."""
+    import glob
+    import time
+    orc = helpers.oracle_for(bench_vocab)
+    data, offs = corpus.generate("mixed", 500, 1024, seed=corpus.BASE_SEED + 9)
+    args = (bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"])
+    monkeypatch.setenv("TK_TABLE_CACHE_DIR", str(tmp_path))
+    t0 = time.perf_counter()
+    e1 = tk.Engine(*args, device=0)            # builds, writes the file
+    t1 = time.perf_counter()
+    files = glob.glob(str(tmp_path / "tk_tables_*.bin"))
+    assert len(files) == 1
+    e2 = tk.Engine(*args, device=0)            # loads
+    t2 = time.perf_counter()
+    check_batch(e1, orc, data, offs)
+    check_batch(e2, orc, data, offs)
+    e1.close()
+    e2.close()
+    print("context create: build+save %.3f s, from cache %.3f s" % (t1 - t0, t2 - t1))
+    raw = open(files[0], "rb").read()
+    open(files[0], "wb").write(raw[:len(raw) // 3])
+    e3 = tk.Engine(*args, device=0)            # refuses the truncated file, builds, rewrites
+    check_batch(e3, orc, data, offs)
+    e3.close()
+    assert open(files[0], "rb").read() == raw

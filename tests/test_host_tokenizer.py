@@ -147,3 +147,37 @@ def test_c_abi_exports(tk):
     L = tk.lib()
     for n in sorted(names):
         assert hasattr(L, n), n
+
+
+def test_table_cache_round_trip(tmp_path, test_vocab, bench_vocab):
+    """the derived device tables written to / read from a side file keyed by the rank table are
+    identical, field by field, to freshly built ones; a wrong key, a truncated or a corrupted file is refused."""
+    import emu
+    r = emu.table_cache_roundtrip(test_vocab["tokens"], test_vocab["num_special"], str(tmp_path / "small.bin"))
+    assert r["file_bytes"] > 0
+    p = tmp_path / "bench.bin"
+    r = emu.table_cache_roundtrip(bench_vocab["tokens"], bench_vocab["num_special"], str(p))
+    assert r["load_s"] < r["build_s"]
+    raw = p.read_bytes()
+    for bad in (raw[:len(raw) // 2], raw[:-1], b"\x00" * 64):
+        q = tmp_path / "bad.bin"
+        q.write_bytes(bad)
+        with pytest.raises(RuntimeError):   # the round trip's own load of a damaged file must fail -> rc != 0
+            _load_only(emu, bench_vocab, str(q))
+
+
+def _load_only(emu, v, path):
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    if not hasattr(L, "_tk_load_only"):
+        L.emu_table_cache_load.restype = ctypes.c_int
+        L._tk_load_only = True
+    toks = v["tokens"]
+    toffs = np.zeros(len(toks) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in toks], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(toks), dtype=np.uint8).copy()
+    rc = L.emu_table_cache_load(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), toffs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                ctypes.c_uint32(len(toks)), ctypes.c_uint32(v["num_special"]), ctypes.c_char_p(path.encode()))
+    if rc != 0:
+        raise RuntimeError("refused")

@@ -479,29 +479,39 @@ Tekkenizer* Tekkenizer::create(const std::vector<TokenInfo>& vocab_in, const std
             return nullptr;
         }
     }
-    Tekkenizer* t = new Tekkenizer();
-    t->vocab_size_ = vocab_size;
-    t->num_special_tokens_ = num_special_tokens;
-    t->version_ = version;
-    t->special_tokens_ = all;
-    t->has_audio_ = has_audio;
-    for (const auto& s : all) t->special_tokens_map_[s.token_str] = s.rank;  // :129-132 (later wins)
-
     // rank-indexed table
     const size_t n_ranks = ranks.size();
     std::vector<const std::string*> by_rank(n_ranks, nullptr);
     size_t total = 0;
     for (const auto& kv : ranks) { by_rank[kv.second] = &kv.first; total += kv.first.size(); }
-    t->offs_.assign(n_ranks + 1, 0);
-    t->blob_.reserve(total + 1);
+    std::vector<uint32_t> offs(n_ranks + 1, 0);
+    std::vector<uint8_t> blob;
+    blob.reserve(total + 1);
     for (size_t r = 0; r < n_ranks; ++r) {
-        t->blob_.insert(t->blob_.end(), by_rank[r]->begin(), by_rank[r]->end());
-        t->offs_[r + 1] = (uint32_t)t->blob_.size();
+        blob.insert(blob.end(), by_rank[r]->begin(), by_rank[r]->end());
+        offs[r + 1] = (uint32_t)blob.size();
     }
+    return assemble(std::move(all), std::move(blob), std::move(offs), vocab_size, num_special_tokens, version, has_audio, device_id, err);
+}
+
+Tekkenizer* Tekkenizer::assemble(std::vector<SpecialTokenInfo>&& all, std::vector<uint8_t>&& blob, std::vector<uint32_t>&& offs,
+                                 uint64_t vocab_size, uint64_t num_special_tokens, const std::string& version, bool has_audio,
+                                 int device_id, TokenizerError& err) {
+    Tekkenizer* t = new Tekkenizer();
+    t->vocab_size_ = vocab_size;
+    t->num_special_tokens_ = num_special_tokens;
+    t->version_ = version;
+    t->special_tokens_ = std::move(all);
+    t->has_audio_ = has_audio;
+    t->blob_ = std::move(blob);
+    t->offs_ = std::move(offs);
+    const std::vector<SpecialTokenInfo>& all_ref = t->special_tokens_;
+    for (const auto& s : all_ref) t->special_tokens_map_[s.token_str] = s.rank;  // :129-132 (later wins)
+    const size_t n_ranks = t->offs_.size() - 1;
     // vocabulary strings, :135-155
     t->vocab_.resize((size_t)vocab_size);
     for (uint64_t i = 0; i < vocab_size; ++i) {
-        if (i < num_special_tokens) t->vocab_[i] = all[i].token_str;
+        if (i < num_special_tokens) t->vocab_[i] = all_ref[i].token_str;
         else {
             const uint64_t r = i - num_special_tokens;
             if (r < n_ranks) t->vocab_[i] = utf8_lossy(t->blob_.data() + t->offs_[r], t->offs_[r + 1] - t->offs_[r]);
@@ -535,8 +545,8 @@ Tekkenizer* Tekkenizer::create(const std::vector<TokenInfo>& vocab_in, const std
         // special-token strings BY POSITION, for the device decode path (Keep policy, :536-540)
         std::string sblob;
         std::vector<uint32_t> soffs(1, 0);
-        for (const auto& s : all) { sblob += s.token_str; soffs.push_back((uint32_t)sblob.size()); }
-        rc = tk_ctx_set_special_tokens(t->ctx_, (const uint8_t*)sblob.data(), soffs.data(), (uint32_t)all.size());
+        for (const auto& s : all_ref) { sblob += s.token_str; soffs.push_back((uint32_t)sblob.size()); }
+        rc = tk_ctx_set_special_tokens(t->ctx_, (const uint8_t*)sblob.data(), soffs.data(), (uint32_t)all_ref.size());
         if (rc != TK_OK) {
             err = mk(rc, std::string("special tokens upload failed: ") + tk_last_error(t->ctx_));
             delete t;
@@ -560,20 +570,148 @@ Tekkenizer* Tekkenizer::from_json(const char* json, size_t len, int device_id, T
                   md.has_audio, device_id, err);
 }
 
-Tekkenizer* Tekkenizer::from_file(const std::string& path, int device_id, TokenizerError& err) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) {
-        err = mk(TK_ERR_IO, "No such file or directory (os error 2): " + path);
-        return nullptr;
+// ---- model cache ----
+// With TK_TABLE_CACHE_DIR set, from_file keeps what it derived from a tekken.json -- the validated rank table, the
+// special tokens and the scalars -- in `<dir>/tk_model_<hash of the file's bytes>.bin`; the next from_file of a file
+// with the same bytes skips the JSON parse, base64 and the rank-map checks (and, through tk_build_tables_cached, the
+// device-table build).  Only a load that SUCCEEDED is ever written, so error behaviour is that of the uncached path; the
+// key is 128 bits over length + content, the file carries magic, version, key, sizes and a tail marker, and anything
+// that does not check out falls back to the JSON.
+#define TK_MODEL_MAGIC 0x4D4B5454u /* "TTKM" */
+#define TK_MODEL_VERSION 1u
+
+static void content_key(const std::string& c, uint64_t key[2]) {
+    uint64_t a = 0xCBF29CE484222325ull ^ c.size(), b = 0x9E3779B97F4A7C15ull + c.size();
+    const size_t n8 = c.size() / 8;
+    const char* p = c.data();
+    for (size_t i = 0; i < n8; ++i) {
+        uint64_t w;
+        memcpy(&w, p + 8 * i, 8);
+        a = (a ^ w) * 0x100000001B3ull;
+        a ^= a >> 29;
+        b = (b + w) * 0xD6E8FEB86659FD93ull;
+        b ^= b >> 32;
     }
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const std::string content = ss.str();
+    uint64_t w = 0;
+    memcpy(&w, p + 8 * n8, c.size() - 8 * n8);
+    a = (a ^ w) * 0x100000001B3ull;
+    b = (b + w) * 0xD6E8FEB86659FD93ull;
+    key[0] = a ^ (a >> 31);
+    key[1] = b ^ (b >> 33);
+}
+
+namespace {
+struct ModelHead {
+    uint32_t magic, version;
+    uint64_t key[2];
+    uint64_t vocab_size, num_special_tokens, n_special, n_ranks, blob_bytes, strings_bytes;
+    uint32_t has_audio, version_len;
+};
+}  // namespace
+
+bool Tekkenizer::save_model_cache(const std::string& path, const uint64_t key[2]) const {
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    std::string strings;                     // version, then per special token: u64 rank, u8 is_control, u32 len, bytes
+    strings += version_;
+    for (const auto& s : special_tokens_) {
+        const uint64_t r = s.rank;
+        const uint8_t ic = s.is_control ? 1 : 0;
+        const uint32_t l = (uint32_t)s.token_str.size();
+        strings.append((const char*)&r, 8);
+        strings.append((const char*)&ic, 1);
+        strings.append((const char*)&l, 4);
+        strings += s.token_str;
+    }
+    ModelHead h;
+    memset(&h, 0, sizeof(h));
+    h.magic = TK_MODEL_MAGIC; h.version = TK_MODEL_VERSION; h.key[0] = key[0]; h.key[1] = key[1];
+    h.vocab_size = vocab_size_; h.num_special_tokens = num_special_tokens_; h.n_special = special_tokens_.size();
+    h.n_ranks = offs_.size() - 1; h.blob_bytes = offs_.back(); h.strings_bytes = strings.size();
+    h.has_audio = has_audio_ ? 1 : 0; h.version_len = (uint32_t)version_.size();
+    const uint32_t tail = TK_MODEL_MAGIC;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(offs_.data(), 4, offs_.size(), f) == offs_.size() &&
+              (h.blob_bytes == 0 || fwrite(blob_.data(), 1, h.blob_bytes, f) == h.blob_bytes) &&
+              (strings.empty() || fwrite(strings.data(), 1, strings.size(), f) == strings.size()) && fwrite(&tail, 4, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());
+    return ok;
+}
+
+Tekkenizer* Tekkenizer::load_model_cache(const std::string& path, const uint64_t key[2], int device_id, TokenizerError& err) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return nullptr;
+    ModelHead h;
+    std::vector<uint32_t> offs;
+    std::vector<uint8_t> blob;
+    std::string strings;
+    uint32_t tail = 0;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && h.magic == TK_MODEL_MAGIC && h.version == TK_MODEL_VERSION && h.key[0] == key[0] &&
+              h.key[1] == key[1] && h.n_ranks < (1ull << 31) && h.blob_bytes < (1ull << 32) && h.strings_bytes < (1ull << 31) &&
+              h.n_special <= h.num_special_tokens && h.n_special < (1ull << 24) && h.version_len <= h.strings_bytes;
+    if (ok) {
+        offs.resize(h.n_ranks + 1);
+        blob.resize(h.blob_bytes);
+        strings.resize(h.strings_bytes);
+        ok = fread(offs.data(), 4, offs.size(), f) == offs.size() && (blob.empty() || fread(blob.data(), 1, blob.size(), f) == blob.size()) &&
+             (strings.empty() || fread(&strings[0], 1, strings.size(), f) == strings.size()) && fread(&tail, 4, 1, f) == 1 &&
+             tail == TK_MODEL_MAGIC && offs[0] == 0 && offs.back() == h.blob_bytes;
+    }
+    fclose(f);
+    for (size_t r = 0; ok && r < h.n_ranks; ++r) ok = offs[r + 1] >= offs[r];
+    if (!ok) return nullptr;
+    std::vector<SpecialTokenInfo> all;
+    size_t q = h.version_len;
+    const std::string version = strings.substr(0, q);
+    for (uint64_t i = 0; i < h.n_special; ++i) {
+        if (q + 13 > strings.size()) return nullptr;
+        uint64_t r; uint8_t ic; uint32_t l;
+        memcpy(&r, &strings[q], 8); ic = (uint8_t)strings[q + 8]; memcpy(&l, &strings[q + 9], 4);
+        q += 13;
+        if (q + l > strings.size()) return nullptr;
+        all.push_back(SpecialTokenInfo{r, strings.substr(q, l), ic != 0});
+        q += l;
+    }
+    if (q != strings.size() || all.size() != h.num_special_tokens) return nullptr;
+    return assemble(std::move(all), std::move(blob), std::move(offs), h.vocab_size, h.num_special_tokens, version, h.has_audio != 0,
+                    device_id, err);
+}
+
+Tekkenizer* Tekkenizer::from_file(const std::string& path, int device_id, TokenizerError& err) {
+    std::string content;
+    {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) {
+            err = mk(TK_ERR_IO, "No such file or directory (os error 2): " + path);
+            return nullptr;
+        }
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0) content.append(buf, got);
+        fclose(f);
+    }
+    const char* dir = getenv("TK_TABLE_CACHE_DIR");
+    uint64_t key[2] = {0, 0};
+    std::string side;
+    if (dir && *dir) {
+        content_key(content, key);
+        char name[80];
+        snprintf(name, sizeof(name), "/tk_model_%016llx%016llx.bin", (unsigned long long)key[0], (unsigned long long)key[1]);
+        side = std::string(dir) + name;
+        err = TokenizerError();
+        Tekkenizer* t = load_model_cache(side, key, device_id, err);
+        if (t) return t;
+        if (!err.ok()) return nullptr;       // the cache was good, the device side failed: same error as the uncached path
+    }
     if (!utf8_valid((const uint8_t*)content.data(), content.size())) {  // read_to_string (:223)
         err = mk(TK_ERR_IO, "stream did not contain valid UTF-8");
         return nullptr;
     }
-    return from_json(content.data(), content.size(), device_id, err);
+    Tekkenizer* t = from_json(content.data(), content.size(), device_id, err);
+    if (t && !side.empty()) (void)t->save_model_cache(side, key);   // best effort
+    return t;
 }
 
 TokenizerError Tekkenizer::get_control_token(const std::string& name, uint32_t& id) const {  // :331-341

@@ -101,6 +101,12 @@ public:
 
 private:
     Tekkenizer() = default;
+    // second half of `create`: everything after the rank table is validated (also the entry of the model cache)
+    static Tekkenizer* assemble(std::vector<SpecialTokenInfo>&& all, std::vector<uint8_t>&& blob, std::vector<uint32_t>&& offs,
+                                uint64_t vocab_size, uint64_t num_special_tokens, const std::string& version, bool has_audio,
+                                int device_id, TokenizerError& err);
+    bool save_model_cache(const std::string& path, const uint64_t key[2]) const;
+    static Tekkenizer* load_model_cache(const std::string& path, const uint64_t key[2], int device_id, TokenizerError& err);
     TokenizerError decode_group(const uint32_t* ids, size_t n, bool is_special, SpecialTokenPolicy policy,
                                 std::vector<std::string>& out) const;
     TokenizerError core_decode(const uint32_t* ranks, size_t n, std::string& out) const;

@@ -181,3 +181,65 @@ def _load_only(emu, v, path):
                                 ctypes.c_uint32(len(toks)), ctypes.c_uint32(v["num_special"]), ctypes.c_char_p(path.encode()))
     if rc != 0:
         raise RuntimeError("refused")
+
+
+def _piece_or_err(tk, t, i):
+    try:
+        return t.id_to_piece(i)
+    except tk.TokenizerError as e:           # a lone non-ASCII byte is not a string (src/tekkenizer.rs:617-640)
+        return ("error", e.kind)
+
+
+def test_model_cache_from_file(tk, small_vocab, bench_vocab, tmp_path, monkeypatch):
+    """Row f-2, file level: with TK_TABLE_CACHE_DIR set, from_file of the same bytes comes from the side file and the
+    object behaves identically; other bytes get their own key; failed loads are never cached; a damaged side file is
+    ignored."""
+    import glob
+    import time
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    P = tk.SpecialTokenPolicy
+    specials = ("<unk>", "<s>", "</s>", "[INST]", "é☃")
+    f1 = tmp_path / "a.json"
+    f1.write_text(json.dumps(model(small_vocab["tokens"], specials=specials)))
+    plain = tk.Tekkenizer.from_file(str(f1), device=-1)
+    monkeypatch.setenv("TK_TABLE_CACHE_DIR", str(cache))
+    first = tk.Tekkenizer.from_file(str(f1), device=-1)       # parses, writes
+    side = glob.glob(str(cache / "tk_model_*.bin"))
+    assert len(side) == 1
+    second = tk.Tekkenizer.from_file(str(f1), device=-1)      # from the side file
+    ids = [1, 266, 42, 129, 121, 124, 118, 110, 4, 2]
+    for t in (first, second):
+        assert (t.vocab_size(), t.num_special_tokens(), t.version()) == (plain.vocab_size(), plain.num_special_tokens(), plain.version())
+        assert t.get_control_token("é☃") == 4 and t.get_control_token("<SPECIAL_7>") == 7
+        assert t.decode(ids, P.Keep) == plain.decode(ids, P.Keep) == "<s>hello worldé☃</s>"
+        assert [_piece_or_err(tk, t, i) for i in range(t.vocab_size())] == [_piece_or_err(tk, plain, i) for i in range(plain.vocab_size())]
+    # different bytes (even if the same model) -> different key
+    f2 = tmp_path / "b.json"
+    f2.write_text(json.dumps(model(small_vocab["tokens"], specials=specials)) + "\n")
+    tk.Tekkenizer.from_file(str(f2), device=-1)
+    assert len(glob.glob(str(cache / "tk_model_*.bin"))) == 2
+    # a file that fails to load leaves nothing behind and fails the same way again
+    f3 = tmp_path / "c.json"
+    f3.write_text(json.dumps(model(small_vocab["tokens"], version="v99")))
+    for _ in range(2):
+        with pytest.raises(tk.TokenizerError) as e:
+            tk.Tekkenizer.from_file(str(f3), device=-1)
+        assert e.value.kind == "InvalidConfig"
+    assert len(glob.glob(str(cache / "tk_model_*.bin"))) == 2
+    # damaged side file: ignored, rewritten
+    raw = open(side[0], "rb").read()
+    for bad in (raw[:len(raw) // 2], raw[:-2], raw[:40] + bytes([raw[40] ^ 1]) + raw[41:60]):
+        open(side[0], "wb").write(bad)
+        t = tk.Tekkenizer.from_file(str(f1), device=-1)
+        assert t.decode(ids, P.Keep) == "<s>hello worldé☃</s>"
+        assert open(side[0], "rb").read() == raw
+    # load time on the bench-size vocabulary (the reference's profiling tests look at exactly this)
+    t0 = time.perf_counter()
+    a = tk.Tekkenizer.from_file(bench_vocab["path"], device=-1)
+    t1 = time.perf_counter()
+    b = tk.Tekkenizer.from_file(bench_vocab["path"], device=-1)
+    t2 = time.perf_counter()
+    print("from_file host-only: parse %.3f s, from cache %.3f s" % (t1 - t0, t2 - t1))
+    assert a.vocab_size() == b.vocab_size() and a.id_to_piece(100000) == b.id_to_piece(100000)
+    assert (t2 - t1) < (t1 - t0)

@@ -48,6 +48,9 @@ def main():
                     g.write(line)
                     if cfg == "c2":
                         bench = json.loads(line)
+    lt = os.path.join(go, "load_time_%s.json" % tag)
+    if os.path.exists(lt):
+        shutil.copy(lt, os.path.join(out, "%s_load_time.json" % tag))
     n_docs = bench["config"]["docs_total"] if bench else 1_000_000
     n_ids = bench["config"]["ids_total"] if bench else 98_128_307
     allc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -74,36 +74,40 @@ struct alignas(16) tk_u32x4 { uint32_t x, y, z, w; };
 // and compared with bitwise ops; there is no probe loop.
 struct alignas(8) tk_u32x2 { uint32_t x, y; };
 
-// Whole-piece lookup.  A probe costs what its scattered load instructions cost (about one lane per clock through the
-// CU's L1), so: pieces of up to 8 bytes -- most of the text -- take ONE 16-byte load (key, rank and length in one
-// entry of KEY8); pieces of 9..16 bytes a 16-byte + an 8-byte load from KEY16; the second cuckoo location is fetched
-// only by the lanes whose first one did not match (first choices are filled first by the builder).
-TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
-    const uint32_t h = tk_key_hash(t.key_hash_mode, k0, k1, k2, k3, len);
-    // KEY8 and KEY16 lanes issue their loads TOGETHER and wait once: a wave that holds pieces of both kinds would
-    // otherwise walk the two tables one after the other, every step a full memory round trip for the whole wave
-    const bool s8 = len <= 8u;
-    const uint8_t* p1 = s8 ? reinterpret_cast<const uint8_t*>(t.key8_tab + (h & t.key8_mask))
-                           : reinterpret_cast<const uint8_t*>(t.key_tab + (h & t.key_mask));
-    tk_u32x4 a = *reinterpret_cast<const tk_u32x4*>(p1);          // KEY8: {k0, k1, rank, len}; KEY16: {k0, k1, k2, k3}
+// Whole-piece lookup.  Pieces of up to 8 bytes -- most of the text -- take ONE 16-byte load (key, rank and length in one
+// entry of KEY8); pieces of 9..16 bytes a 16-byte + an 8-byte load from KEY16, whose first 16 bytes have the KEY8 layout:
+// a short piece has k2 = k3 = 0 and loads nothing for them, so ONE compare sequence without selects serves both.  The
+// second cuckoo location is fetched only by the lanes whose first one did not match AND is flagged (first choices are
+// filled first by the builder; an unflagged slot that does not match is a definite miss).
+// One location: rank or TK_RANK_MAX; *lw = the slot's length word (TK_KEY_SPILL = something spilled from here).
+TK_DEV uint32_t tk_key_slot(const uint8_t* p, bool s8, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len, uint32_t* lw) {
+    tk_u32x4 a = *reinterpret_cast<const tk_u32x4*>(p);           // {k0, k1, rank, len | flag}
     tk_u32x2 b;
     b.x = 0u; b.y = 0u;
-    if (!s8) b = *reinterpret_cast<const tk_u32x2*>(p1 + 16);     // KEY16: {rank, len}
-    WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
-    const uint32_t lw = s8 ? a.w : b.y;                          // len | spill flag of the slot
-    uint32_t d = s8 ? ((a.x ^ k0) | (a.y ^ k1)) : ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3));
-    d |= (lw & ~TK_KEY_SPILL) ^ len;
-    if (d == 0u) return s8 ? a.z : b.x;
-    if (!(lw & TK_KEY_SPILL)) return TK_RANK_MAX;                // nothing spilled from this slot: a definite miss
-    // second location (first choices are filled first by the builder: few lanes get here)
-    const uint32_t h2 = tk_hash_alt(h);
-    const uint8_t* p2 = s8 ? reinterpret_cast<const uint8_t*>(t.key8_tab + (h2 & t.key8_mask))
-                           : reinterpret_cast<const uint8_t*>(t.key_tab + (h2 & t.key_mask));
-    a = *reinterpret_cast<const tk_u32x4*>(p2);
-    if (!s8) b = *reinterpret_cast<const tk_u32x2*>(p2 + 16);
-    WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);
-    d = s8 ? ((a.x ^ k0) | (a.y ^ k1) | ((a.w & ~TK_KEY_SPILL) ^ len)) : ((a.x ^ k0) | (a.y ^ k1) | (a.z ^ k2) | (a.w ^ k3) | ((b.y & ~TK_KEY_SPILL) ^ len));
-    return d == 0u ? (s8 ? a.z : b.x) : TK_RANK_MAX;              // an empty entry has len 0
+    if (!s8) b = *reinterpret_cast<const tk_u32x2*>(p + 16);      // KEY16: {k2, k3}
+    WV_PIN(a.x); WV_PIN(a.y); WV_PIN(a.z); WV_PIN(a.w); WV_PIN(b.x); WV_PIN(b.y);   // both loads before the first compare
+    const uint32_t d = (a.x ^ k0) | (a.y ^ k1) | ((a.w & ~TK_KEY_SPILL) ^ len) | (b.x ^ k2) | (b.y ^ k3);
+    *lw = a.w;
+    return d == 0u ? a.z : TK_RANK_MAX;                           // an empty entry has len 0
+}
+// h = tk_key_hash of the key; KEY8 / KEY16 lanes issue their loads TOGETHER and wait once
+TK_DEV uint32_t tk_probe_key_h(const uint8_t* key8_tab, uint32_t key8_mask, const uint8_t* key16_tab, uint32_t key16_mask, uint32_t h,
+                               uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    const bool s8 = len <= 8u;
+    const uint8_t* base = s8 ? key8_tab : key16_tab;
+    const uint32_t o1 = s8 ? (h & key8_mask) << 4 : (h & key16_mask) << 5;
+    uint32_t lw;
+    uint32_t r = tk_key_slot(base + o1, s8, k0, k1, k2, k3, len, &lw);
+    if (r == TK_RANK_MAX && (lw & TK_KEY_SPILL)) {
+        const uint32_t h2 = tk_hash_alt(h);
+        const uint32_t o2 = s8 ? (h2 & key8_mask) << 4 : (h2 & key16_mask) << 5;
+        r = tk_key_slot(base + o2, s8, k0, k1, k2, k3, len, &lw);
+    }
+    return r;
+}
+TK_DEV uint32_t tk_probe_key(const TkTablesView& t, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t len) {
+    return tk_probe_key_h(reinterpret_cast<const uint8_t*>(t.key8_tab), t.key8_mask, reinterpret_cast<const uint8_t*>(t.key_tab), t.key_mask,
+                          tk_key_hash(t.key_hash_mode, k0, k1, k2, k3, len), k0, k1, k2, k3, len);
 }
 
 // text points at the piece bytes in the packed buffer; a tag match is verified byte by byte so

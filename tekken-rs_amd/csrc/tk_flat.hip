@@ -38,24 +38,42 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
 }
 
-__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
-    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+template <int DBG, int MODE>
+__device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_t* lds_all) {
     const int lane = wv_lane();
-    uint32_t* lds = lds_all + (threadIdx.x >> 6) * TKF_LDS_WORDS;
-    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
-    tk_flat_init_lds(lds, lane);
-    uint64_t c_begin = wave, c_end = a.n_chunks, c_step = n_waves;
+    // the wave number is wave-uniform: say so, and the chunk index and everything addressed by it stay in scalar registers
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* lds = lds_all + wv * TKF_LDS_WORDS;
+    tk_flat_init_lds(a, lds, lane);
+    uint64_t c_begin = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + wv, c_end = a.n_chunks, c_step = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
     if (gridDim.x >= 8) {
         // XCD-aware: blocks b and b + 8 share an XCD (and its L2), so the blocks of one residue class take ONE contiguous
         // eighth of the chunks -- neighbouring chunks share their halo bytes and the cache lines of the per-chunk /
         // per-document arrays they read and write.  (Placement is a speed matter only.)
         const uint64_t label = blockIdx.x & 7u, nb = (gridDim.x - label + 7u) / 8u;
-        c_begin = a.n_chunks * label / 8 + (uint64_t)(blockIdx.x >> 3) * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
+        c_begin = a.n_chunks * label / 8 + (uint64_t)(blockIdx.x >> 3) * (TKF_BLOCK / 64) + wv;
         c_end = a.n_chunks * (label + 1) / 8;
         c_step = nb * (TKF_BLOCK / 64);
     }
-    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk(a, c, lane, lds);
+    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE>(a, c, lane, lds);
+}
+
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+    tk_flat_kernel_body<0, 0>(a, lds_all);
+}
+
+// the tables were built with the strong key hash (mode 1: the cheap one could not place the vocabulary)
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_mode1_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+    tk_flat_kernel_body<0, 1>(a, lds_all);
+}
+
+// the same kernels with the timing ablations / per-byte split flags compiled in (TK_DEBUG_ABLATE, tk_split_batch)
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_dbg_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+    if (a.t.key_hash_mode == 0u) tk_flat_kernel_body<1, 0>(a, lds_all);
+    else tk_flat_kernel_body<1, 1>(a, lds_all);
 }
 
 // wave w of tk_merge_kernel starts with item 64 w: note down which sub-queue holds it (thread e owns the waves whose
@@ -308,7 +326,9 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
         if (cap == 0) cap = 1280;
     }
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -49,7 +49,11 @@
                                                         words of the piece list, which is built in step 5) */
 #define TKF_L_KM (TKF_L_BPFX + 64)                  /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
 #define TKF_L_TXT (TKF_L_KM + 17 * 4)                /* [256 + 4] the region's bytes: a piece's 16 bytes are read from here */
-#define TKF_LDS_WORDS (TKF_L_TXT + 256 + 4)
+#define TKF_L_CONST (TKF_L_TXT + 256 + 4)              /* [8] wave-uniform constants of the probe: KEY8 mask, KEY16 mask, KEY8 base, KEY16 base.
+                                                        The kernel is out of scalar registers (spilled SGPRs come back through
+                                                        v_readlane, a VALU slot each, and VALU issue is what bounds it); an LDS
+                                                        broadcast read costs an LDS slot, of which it has plenty */
+#define TKF_LDS_WORDS (TKF_L_CONST + 8)
 
 
 // ------------------------------------------------------------------------------------------
@@ -250,7 +254,14 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
 // one chunk
 // ------------------------------------------------------------------------------------------
 // once per wave, before its first chunk: the key byte masks
-TK_DEV void tk_flat_init_lds(uint32_t* lds, int lane) {
+TK_DEV void tk_flat_init_lds(const TkFlatArgs& a, uint32_t* lds, int lane) {
+    if (lane == 63) {
+        const uint64_t b8 = (uint64_t)reinterpret_cast<uintptr_t>(a.t.key8_tab), b16 = (uint64_t)reinterpret_cast<uintptr_t>(a.t.key_tab);
+        lds[TKF_L_CONST + 0] = a.t.key8_mask;
+        lds[TKF_L_CONST + 1] = a.t.key_mask;
+        lds[TKF_L_CONST + 2] = (uint32_t)b8; lds[TKF_L_CONST + 3] = (uint32_t)(b8 >> 32);
+        lds[TKF_L_CONST + 4] = (uint32_t)b16; lds[TKF_L_CONST + 5] = (uint32_t)(b16 >> 32);
+    }
     if (lane <= 16) {
         for (int q = 0; q < 4; ++q) {
             const int keep = lane - 4 * q;
@@ -262,6 +273,10 @@ TK_DEV void tk_flat_init_lds(uint32_t* lds, int lane) {
 
 TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
+// DBG = 0: the production instantiation.  DBG = 1 adds the timing ablations (TK_DEBUG_ABLATE) and the per-byte piece-start
+// flags of tk_split_batch: every one of those tests costs scalar registers and VALU slots the kernel does not have.
+// MODE = the key hash the tables were built with (TkTablesView::key_hash_mode), a compile-time constant here.
+template <int DBG, int MODE>
 TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
     const int64_t n = (int64_t)a.n_bytes;
@@ -334,7 +349,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         m.S |= cl[128 + lane];
         m.nmb = wv_ballot(nmb) != 0ull;
     }
-    if (a.dbg_ablate & 16) {
+    if (DBG && (a.dbg_ablate & 16)) {
         // (keeps the work alive without producing slot counts: the downstream kernels must see an empty chunk)
         const uint32_t v = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
         if (lane == 0) {
@@ -369,7 +384,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // ---- 3. piece starts ---------------------------------------------------------------------------
     uint32_t SPR, cont;
     const uint32_t PS = tkf_rules(m, DS, lane, &SPR, &cont);
-    if (a.dbg_ablate & 8) {
+    if (DBG && (a.dbg_ablate & 8)) {
         if (lane == 0) {
             a.kcount[c] = (PS + SPR + cont) == 0xFFFFFFFFu ? 1u : 0u;
             for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
@@ -377,7 +392,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         return;
     }
     const uint32_t commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
-    if (a.dbg_starts) {
+    if (DBG && a.dbg_starts) {
         for (int k = 0; k < 16; ++k)
             if ((commit_mask >> k) & 1u) a.dbg_starts[r0 + 16 * lane + k] = (PS >> k) & 1u;
     }
@@ -441,42 +456,50 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // queued for tk_merge_wave; the slots it does not fill stay TKF_HOLE and are squeezed out by the assembly.
     const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
     uint32_t* tmp = a.tmp + c * TKF_STRIDE;
+    uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
     uint32_t E = 0;                                         // slots beyond one per piece so far
     uint32_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;
     const uint32_t nbatch = (np_own + 63u) / 64u;
     for (uint32_t j = 0; j < nbatch; ++j) {
+        // Straight-line for the common case (a piece of up to 16 bytes): every lane fetches bytes and hashes -- a lane
+        // without a piece takes position 0, length 1 -- and only the table loads are predicated.
         const uint32_t idx = j * 64u + (uint32_t)lane;
         const bool act = idx < np_own;
-        uint32_t pos = 0, len = 1;
-        if (act) {
-            pos = list[idx];
-            len = (uint32_t)list[idx + 1] - pos;
+        const uint32_t p0 = list[idx], p1 = list[idx + 1];  // (idx + 1 <= 960: inside the list words, whatever they hold)
+        const uint32_t pos = act ? p0 : 0u;
+        const uint32_t len = act ? p1 - p0 : 1u;
+        // the piece's first 16 bytes from the LDS copy of the region (five aligned dwords, funnel-shifted), zeroed past the
+        // piece (masks by length from LDS)
+        uint32_t kk[4];
+        {
+            const uint32_t* tw = lds + TKF_L_TXT + (pos >> 2);
+            const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4];
+            const uint32_t sh = pos & 3u;
+            const uint32_t* km = lds + TKF_L_KM + 4u * (len < 16u ? len : 16u);
+            kk[0] = wv_alignbyte(t1, t0, sh) & km[0]; kk[1] = wv_alignbyte(t2, t1, sh) & km[1];
+            kk[2] = wv_alignbyte(t3, t2, sh) & km[2]; kk[3] = wv_alignbyte(t4, t3, sh) & km[3];
         }
-        uint32_t r = 0;
-        bool toolong = false;
-        if (a.dbg_ablate & 1) {
+        uint32_t r = kk[0];                                 // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
+        if (DBG && (a.dbg_ablate & 1)) {
             r = 7u;
-        } else if (act) {
+        } else if (DBG && (a.dbg_ablate & 64)) {
+            r = (kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) & 0xFFFFu;                                            // timing: no hash, no table
+        } else {
+            const uint32_t h = tk_key_hash((uint32_t)MODE, kk[0], kk[1], kk[2], kk[3], len);
+            if (DBG && (a.dbg_ablate & 128)) {
+                r = h & 0xFFFFu;                                                                      // timing: no table
+            } else if (len - 2u <= 14u) {                   // 2..16 bytes: exact-key probe
+                const uint32_t* kc = lds + TKF_L_CONST;
+                const uint64_t b8 = (uint64_t)kc[2] | ((uint64_t)kc[3] << 32), b16 = (uint64_t)kc[4] | ((uint64_t)kc[5] << 32);
+                r = tk_probe_key_h(reinterpret_cast<const uint8_t*>((uintptr_t)b8), kc[0], reinterpret_cast<const uint8_t*>((uintptr_t)b16), kc[1],
+                                   h, kk[0], kk[1], kk[2], kk[3], len);
+            }
+        }
+        bool toolong = false;
+        if (wv_ballot(len > 16u)) {                         // rare: polynomial hash over the bytes, LONG table; > 64: hand back
             if (len > 64u) {
                 toolong = true;
-            } else if (len <= 16u) {
-                // the piece's first 16 bytes from the LDS copy of the region (five aligned dwords, funnel-shifted; a single
-                // byte takes its rank from here too): a scattered 16-byte global load per lane is what this kernel can
-                // least afford
-                const uint32_t* tw = lds + TKF_L_TXT + (pos >> 2);
-                const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4];
-                const uint32_t sh = pos & 3u;
-                uint32_t kk[4];
-                kk[0] = wv_alignbyte(t1, t0, sh); kk[1] = wv_alignbyte(t2, t1, sh);
-                kk[2] = wv_alignbyte(t3, t2, sh); kk[3] = wv_alignbyte(t4, t3, sh);
-                // zero the bytes past the piece (masks by length from LDS)
-                const uint32_t* km = lds + TKF_L_KM + 4u * len;
-                kk[0] &= km[0]; kk[1] &= km[1]; kk[2] &= km[2]; kk[3] &= km[3];
-                // rank of a single byte is the byte (src/tekkenizer.rs:793-798); longer pieces: exact-key probe
-                if (a.dbg_ablate & 64) r = (kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) & 0xFFFFu;                       // timing: no hash, no table
-                else if (a.dbg_ablate & 128) r = tk_key_hash(t.key_hash_mode, kk[0], kk[1], kk[2], kk[3], len) & 0xFFFFu;  // timing: no table
-                else r = len == 1u ? kk[0] : tk_probe_key(t, kk[0], kk[1], kk[2], kk[3], len);
-            } else {
+            } else if (len > 16u && !(DBG && (a.dbg_ablate & 1))) {
                 uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
                 for (uint32_t q = 0; q < len; ++q) {
                     const uint32_t b = rbytes[pos + q];
@@ -485,37 +508,36 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 }
                 r = tk_probe_long(t, h1, h2, len, rbytes + pos);
             }
+            if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> 4), 1u << (pos & 15));
         }
-        if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> 4), 1u << (pos & 15));
-        const bool miss = act && !toolong && r == TK_RANK_MAX && !(a.dbg_ablate & 2);
-        const uint64_t MB = wv_ballot(miss);
+        // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
+        const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
         uint32_t slot = idx + E;
-        if (MB) {
-            // slots of the batch: one per piece + (len - 1) more for every miss before it
+        if (wv_ballot(miss)) {
+            // A miss reserves `len` id slots (it cannot produce more ids than bytes): one per piece + (len - 1) more for
+            // every miss before it.  The misses are queued in the chunk's own region (no global atomics), records in
+            // piece order, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one
+            // class per wave.  Rank inside the class: ONE scan over four packed 8-bit counters (<= 64 misses per batch).
             uint32_t tot;
             slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
             E += tot;
-            // queue the misses in the chunk's own region (no global atomics), records in piece order, one sub-queue per
-            // length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one class per wave
-            const uint32_t cls = len <= 8u ? 0u : len <= 16u ? 1u : len <= 32u ? 2u : 3u;
-            const uint64_t M0 = wv_ballot(miss && cls == 0u), M1 = wv_ballot(miss && cls == 1u);
-            const uint64_t M2 = wv_ballot(miss && cls == 2u), M3 = MB & ~(M0 | M1 | M2);
+            const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
+            const uint32_t sh = cls * 8u;
+            uint32_t ctot;
+            const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
             if (miss) {
-                const uint64_t Mk = cls == 0u ? M0 : cls == 1u ? M1 : cls == 2u ? M2 : M3;
-                const uint32_t nk = cls == 0u ? nm0 : cls == 1u ? nm1 : cls == 2u ? nm2 : nm3;
-                const uint32_t off = cls == 0u ? TKF_MISSOFF0 : cls == 1u ? TKF_MISSOFF1 : cls == 2u ? TKF_MISSOFF2 : TKF_MISSOFF3;
-                a.miss_list[c * TKF_MISSCAP + off + nk + (uint32_t)tk_popc64(Mk & tk_lowmask(lane))] =
-                    pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
+                const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
+                mq[qb + before] = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
             }
-            nm0 += (uint32_t)tk_popc64(M0);
-            nm1 += (uint32_t)tk_popc64(M1);
-            nm2 += (uint32_t)tk_popc64(M2);
-            nm3 += (uint32_t)tk_popc64(M3);
+            nm0 += ctot & 0xFFu;
+            nm1 += (ctot >> 8) & 0xFFu;
+            nm2 += (ctot >> 16) & 0xFFu;
+            nm3 += ctot >> 24;
         }
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
             list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
-            if (!miss && !(a.dbg_ablate & 4)) tmp[slot] = r + t.num_special;
+            if (!miss && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
         }
     }
     if (lane == 0) {

@@ -39,10 +39,13 @@
 #define TK_KEY_SPILL 0x80000000u         /* in the len word of a KEY8 / KEY16 slot: some key whose FIRST choice is this slot lives in its second
                                             choice; clear => a probe that does not match here is a definite miss (no second fetch) */
 
-struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 9..16 bytes, exact 128-bit key */
-    uint32_t k[4];                       /* piece bytes little-endian, zero padded */
+struct alignas(32) tk_key_entry {        /* 32 B, len == 0 <=> empty: pieces of 9..16 bytes, exact 128-bit key.  The first 16 bytes
+                                            read like a KEY8 entry (a piece of up to 8 bytes has k2 = k3 = 0): one compare
+                                            sequence serves both tables, no per-lane selects */
+    uint32_t k01[2];                     /* piece bytes 0..7 little-endian */
     uint32_t rank;
-    uint32_t len;                        /* 9..16 */
+    uint32_t len;                        /* 9..16 | TK_KEY_SPILL */
+    uint32_t k23[2];                     /* piece bytes 8..15, zero padded */
     uint32_t pad[2];
 };
 

@@ -111,7 +111,8 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
     out.n_long = n_long;
     uint32_t lcap = pow2_at_least(2 * n_long + 1);
     out.long_mask = lcap - 1;
-    std::vector<tk_key_entry> key_entries;
+    struct KeyEnt { uint32_t k[4], rank, len; };   // placement works on this; the device layouts are written at the end
+    std::vector<KeyEnt> key_entries;
     key_entries.reserve(n_key);
     out.long_tab.assign(lcap, tk_long_entry{0, 0, 0, 0});
     out.pair2.assign(65536, TK_RANK_MAX);
@@ -123,7 +124,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         if (len >= 2 && len <= 16) {
             uint32_t k[4] = {0, 0, 0, 0};
             for (uint32_t j = 0; j < len; ++j) k[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
-            key_entries.push_back(tk_key_entry{{k[0], k[1], k[2], k[3]}, r, len, {0, 0}});
+            key_entries.push_back(KeyEnt{{k[0], k[1], k[2], k[3]}, r, len});
         } else if (len >= 17) {
             uint32_t h1 = 0, h2 = 0;
             for (uint32_t k = 0; k < len; ++k) {
@@ -141,14 +142,14 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
     // initial capacity and at twice that; if the vocabulary cannot be placed (structured collisions of the fold), the
     // strong hash (mode 1) is used and the tables grown until they fit.
     {
-        std::vector<tk_key_entry> e8, e16;
-        for (const tk_key_entry& e : key_entries) (e.len <= 8 ? e8 : e16).push_back(e);
-        auto place = [&](const std::vector<tk_key_entry>& ents, uint32_t mode, uint32_t cap, std::vector<tk_key_entry>& tab) -> bool {
+        std::vector<KeyEnt> e8, e16;
+        for (const KeyEnt& e : key_entries) (e.len <= 8 ? e8 : e16).push_back(e);
+        auto place = [&](const std::vector<KeyEnt>& ents, uint32_t mode, uint32_t cap, std::vector<KeyEnt>& tab) -> bool {
             const uint32_t mask = cap - 1;
-            tab.assign(cap, tk_key_entry{{0, 0, 0, 0}, 0, 0, {0, 0}});
+            tab.assign(cap, KeyEnt{{0, 0, 0, 0}, 0, 0});
             uint32_t rnd = 0x9E3779B9u;
-            for (const tk_key_entry& e0 : ents) {
-                tk_key_entry e = e0;
+            for (const KeyEnt& e0 : ents) {
+                KeyEnt e = e0;
                 uint32_t avoid = 0xFFFFFFFFu;
                 for (int kicks = 0;; ++kicks) {
                     const uint32_t h = tk_key_hash(mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len);
@@ -166,25 +167,25 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
             return true;
         };
         const uint32_t cap8_0 = pow2_at_least(3 * e8.size() + 1), cap16_0 = pow2_at_least(3 * e16.size() + 1);
-        std::vector<tk_key_entry> t8;
+        std::vector<KeyEnt> t8, t16;
         bool done = false;
         for (int attempt = 0; !done; ++attempt) {
             const uint32_t mode = attempt < 2 ? 0u : 1u;
             const int grow = attempt < 2 ? attempt : attempt - 2;
-            if (((uint64_t)cap8_0 << grow) > (1ull << 30) || ((uint64_t)cap16_0 << grow) > (1ull << 30)) {
+            if (((uint64_t)cap8_0 << grow) > (1ull << 27) || ((uint64_t)cap16_0 << grow) > (1ull << 26)) {   // byte offsets stay below 2^31
                 err = "could not place the vocabulary in the KEY tables";
                 return TK_ERR_INVALID_CONFIG;
             }
             out.key_hash_mode = mode;
             out.key8_mask = (cap8_0 << grow) - 1;
             out.key_mask = (cap16_0 << grow) - 1;
-            done = place(e8, mode, cap8_0 << grow, t8) && place(e16, mode, cap16_0 << grow, out.key_tab);
+            done = place(e8, mode, cap8_0 << grow, t8) && place(e16, mode, cap16_0 << grow, t16);
         }
         // spill flags: slot s is flagged iff a key whose first choice is s was placed in its second choice
-        auto flag = [&](std::vector<tk_key_entry>& tab, uint32_t mask) {
+        auto flag = [&](std::vector<KeyEnt>& tab, uint32_t mask) {
             std::vector<uint32_t> spill;
             for (uint32_t sl = 0; sl <= mask; ++sl) {
-                const tk_key_entry& e = tab[sl];
+                const KeyEnt& e = tab[sl];
                 if (e.len == 0) continue;
                 const uint32_t s1 = tk_key_hash(out.key_hash_mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len) & mask;
                 if (s1 != sl) { spill.push_back(s1); ++out.n_key_second; }
@@ -195,9 +196,12 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
             }
         };
         flag(t8, out.key8_mask);
-        flag(out.key_tab, out.key_mask);
+        flag(t16, out.key_mask);
         out.key8_tab.resize(t8.size());
         for (size_t i = 0; i < t8.size(); ++i) out.key8_tab[i] = tk_key8_entry{{t8[i].k[0], t8[i].k[1]}, t8[i].rank, t8[i].len};
+        out.key_tab.resize(t16.size());
+        for (size_t i = 0; i < t16.size(); ++i)
+            out.key_tab[i] = tk_key_entry{{t16[i].k[0], t16[i].k[1]}, t16[i].rank, t16[i].len, {t16[i].k[2], t16[i].k[3]}, {0, 0}};
     }
 
     // PAIR: every split of every token whose halves are both tokens
@@ -271,7 +275,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
 // table cache (row f-2)
 // ------------------------------------------------------------------------------------------
 #define TK_CACHE_MAGIC 0x42544B54u /* "TKTB" */
-#define TK_CACHE_VERSION 3u        /* bump whenever a table layout or a hash function changes */
+#define TK_CACHE_VERSION 4u        /* bump whenever a table layout or a hash function changes */
 
 static uint64_t fnv1a64(uint64_t h, const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;

@@ -127,8 +127,12 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     uint64_t ops = 0;
     if (n_chunks) {
         tkemu::run_wave([&](int lane) {
-            tk_flat_init_lds(lds.data(), lane);
-            for (uint64_t c = 0; c < n_chunks; ++c) tk_flat_chunk(fa, c, lane, lds.data());
+            tk_flat_init_lds(fa, lds.data(), lane);
+            for (uint64_t c = 0; c < n_chunks; ++c) {
+                const bool m1 = fa.t.key_hash_mode != 0u;
+                if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0>(fa, c, lane, lds.data()); }
+                else { if (m1) tk_flat_chunk<0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<0, 0>(fa, c, lane, lds.data()); }   // production
+            }
         });
         ops += tkemu::g_wave->n_ops;
         std::vector<uint64_t> mpfx(4 * n_chunks + 1, 0);

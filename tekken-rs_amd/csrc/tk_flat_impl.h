@@ -59,8 +59,10 @@
 // ------------------------------------------------------------------------------------------
 // lane-layout mask primitives (16 bits per lane, bit i of lane l = region byte 16 l + i)
 // ------------------------------------------------------------------------------------------
-TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return ((x << k) | (wv_dn1(x) >> (TKF_W - k))) & TKF_WM; }  // 1 <= k <= 16
-TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return ((x >> k) | (wv_up1(x) << (TKF_W - k))) & TKF_WM; }
+// (own word above / below the neighbour's in one register, then ONE bit-field extract: 3 VALU per shift, and the
+// combined word is shared by shifts of the same mask)
+TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return (((x << TKF_W) | wv_dn1(x)) >> (TKF_W - k)) & TKF_WM; }  // 1 <= k <= 16
+TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return (((wv_up1(x) << TKF_W) | x) >> k) & TKF_WM; }
 TK_DEV uint32_t tkf_shl_any(uint32_t x, int k, int lane) {
     const int q = k >> 4, r = k & 15;
     const int s1 = lane - q, s2 = lane - q - 1;
@@ -391,7 +393,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
         return;
     }
-    const uint32_t commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
+    // bits of the commit range [ca, cb): whole lanes 2..59 for every chunk but the last one of the stream
+    uint32_t commit_mask = (uint32_t)(lane - TKF_HL / 16) < (uint32_t)(TKF_COMMIT / 16) ? TKF_WM : 0u;
+    if (cb != TKF_HL + TKF_COMMIT)
+        commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
     if (DBG && a.dbg_starts) {
         for (int k = 0; k < 16; ++k)
             if ((commit_mask >> k) & 1u) a.dbg_starts[r0 + 16 * lane + k] = (PS >> k) & 1u;
@@ -491,7 +496,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             } else if (len - 2u <= 14u) {                   // 2..16 bytes: exact-key probe
                 const uint32_t* kc = lds + TKF_L_CONST;
                 const uint64_t b8 = (uint64_t)kc[2] | ((uint64_t)kc[3] << 32), b16 = (uint64_t)kc[4] | ((uint64_t)kc[5] << 32);
-                r = tk_probe_key_h(reinterpret_cast<const uint8_t*>((uintptr_t)b8), kc[0], reinterpret_cast<const uint8_t*>((uintptr_t)b16), kc[1],
+                r = tk_probe_key_h(wv_global_ptr(b8), kc[0], wv_global_ptr(b16), kc[1],
                                    h, kk[0], kk[1], kk[2], kk[3], len);
             }
         }

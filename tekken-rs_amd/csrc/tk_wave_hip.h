@@ -100,6 +100,13 @@ TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {
 // bytes sh..sh+3 of the 8 bytes {hi:lo} (v_alignbyte_b32), sh in 0..3
 TK_DEV uint32_t wv_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 
+// a device address kept as an integer (e.g. in LDS) back as a pointer: say that it is GLOBAL memory, or the loads through it
+// become flat_load (generic address space: slower path, counts against the LDS counter as well)
+TK_DEV const uint8_t* wv_global_ptr(uint64_t addr) {
+    typedef const uint8_t __attribute__((address_space(1))) * gptr_t;
+    return (const uint8_t*)reinterpret_cast<gptr_t>(addr);
+}
+
 // "this value is needed HERE": keeps the compiler from sinking the load that produces it behind a later branch (it
 // otherwise turns independent loads into a chain of conditional ones -- each a full memory round trip)
 #define WV_PIN(x) asm volatile("" : "+v"(x))

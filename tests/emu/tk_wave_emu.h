@@ -230,5 +230,6 @@ TK_DEV uint32_t wv_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 
 #define WV_PIN(x) ((void)(x))
+TK_DEV const uint8_t* wv_global_ptr(uint64_t addr) { return reinterpret_cast<const uint8_t*>((uintptr_t)addr); }
 
 #endif

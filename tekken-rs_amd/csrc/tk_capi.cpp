@@ -65,6 +65,7 @@ struct tk_ctx {
     float pipeline_ms = 0.f, encode_ms = 0.f;
     uint64_t n_long_docs = 0;
     uint32_t* dbg_mark = nullptr;  // pinned host memory, only with TK_DEBUG_MARKS
+    uint32_t* h_pin = nullptr;     // pinned host words: the per-batch device counters land here with ONE copy
 };
 
 #define TK_HIP(ctx, call)                                                                          \
@@ -118,6 +119,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     }
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
+    if (hipHostMalloc((void**)&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(TK_ERR_RUNTIME); }
 
     const TkHostTables& h = c->host;
     if (getenv("TK_DEBUG_LOG"))
@@ -177,6 +179,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }
 
@@ -331,9 +334,8 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     const uint64_t* d_P = d_pfx + 4 * n_chunks;                // chunk slot prefix sums (offset by the miss total: only differences are used)
     TK_HIP(c, c->out_ids.reserve((n_bytes + 2 * n_docs + 64) * 4));
     TK_HIP(c, hipEventRecord(c->ev[3], s));
-    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, s));
-    TK_HIP(c, hipMemsetAsync(c->f_flags.p, 0, 2 * (n_docs + 1) * 4, s));   // flags | holes
-    TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, s));
+    // (the pre-pass also clears the per-document flags / holes and the 16 counter words: no memset launches)
+    TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, fa.flags, fa.holes, (uint32_t*)c->counters.p, s));
     TK_HIP(c, hipEventRecord(c->ev[0], s));
     TK_HIP(c, tk_launch_flat(fa, s));
     TK_HIP(c, hipEventRecord(c->ev[1], s));
@@ -356,11 +358,13 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
                                           (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id,
-                                          c->host.eos_id, add_bos, add_eos, s));
+                                          c->host.eos_id, add_bos, add_eos, (uint64_t*)((uint32_t*)c->counters.p + 6), s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
-        TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
-        if (!final_pass) TK_HIP(c, hipMemcpyAsync(&n_todo, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
+        // counters 4 (handed-back documents) and 6..7 (total ids, left there by the assembly): one copy into pinned memory
+        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 32, hipMemcpyDeviceToHost, s));
         TK_HIP(c, hipStreamSynchronize(s));
+        memcpy(&total, c->h_pin + 6, 8);
+        if (!final_pass) n_todo = c->h_pin[4];
         return TK_OK;
     };
     int rc = finish(0);

@@ -24,11 +24,15 @@
 #endif
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
-                                                                      uint64_t n_chunks, uint32_t* __restrict__ first_doc) {
+                                                                      uint64_t n_chunks, uint32_t* __restrict__ first_doc,
+                                                                      uint32_t* __restrict__ flags, uint32_t* __restrict__ holes,
+                                                                      uint32_t* __restrict__ counters16) {
     // first_doc[c] = number of documents d with doc_offs[d] < lo(c), lo(c) = max(c * COMMIT - HL, 0);
     // document d owns the chunks whose lo lies in (doc_offs[d], doc_offs[d + 1]]  (the last document: everything above)
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
     if (d == 0 && n_chunks) first_doc[0] = 0u;
+    if (d < 16) counters16[d] = 0u;                 // the batch's device counters
+    if (d <= n_docs) { flags[d] = 0u; holes[d] = 0u; }
     if (d >= n_docs) return;
     const uint64_t s = doc_offs[d], e = doc_offs[d + 1];
     const uint64_t c_lo = (s + TKF_HL) / TKF_COMMIT + 1;
@@ -191,6 +195,7 @@ struct TkFlatAssembleArgs {
     uint32_t* out_ids;
     uint32_t bos_id, eos_id;
     int add_bos, add_eos;
+    uint64_t* total_out;      // receives out_offs[n_docs] (the host reads it with the other counters)
 };
 
 // generic copy of one document (any number of chunks / slots, or a handed-back document)
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
+    if (wave == 0 && lane == 0) *a.total_out = a.out_offs[a.n_docs];
     for (uint64_t d0 = wave * 64; d0 < a.n_docs; d0 += n_waves * 64) {
         const uint64_t dm = d0 + (uint64_t)lane;
         TkFlatDocInfo mine;
@@ -304,10 +310,10 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
 static uint32_t tkf_blocks(uint64_t n_threads) { return (uint32_t)((n_threads + TKF_BLOCK - 1) / TKF_BLOCK); }
 
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
-                                   hipStream_t s) {
-    if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_flat_firstdoc_kernel, dim3(tkf_blocks(n_docs ? n_docs : 1)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs,
-                       n_chunks, first_doc);
+                                   uint32_t* flags, uint32_t* holes, uint32_t* counters16, hipStream_t s) {
+    // (always launched: it also clears flags / holes [n_docs + 1] and the counters)
+    hipLaunchKernelGGL(tk_flat_firstdoc_kernel, dim3(tkf_blocks(n_docs + 16)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs,
+                       n_chunks, first_doc, flags, holes, counters16);
     return hipGetLastError();
 }
 
@@ -363,9 +369,10 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
 
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
-                                   uint32_t eos_id, int add_bos, int add_eos, hipStream_t s) {
+                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     TkFlatAssembleArgs a;
+    a.total_out = total_out;
     a.n_docs = n_docs; a.info = (const TkFlatDocInfo*)doc_info; a.kcount = kcount; a.out_offs = out_offs;
     a.tmp = tmp; a.staging = staging; a.out_ids = out_ids;
     a.bos_id = bos_id; a.eos_id = eos_id; a.add_bos = add_bos; a.add_eos = add_eos;

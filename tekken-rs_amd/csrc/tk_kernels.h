@@ -26,7 +26,7 @@ hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, ui
 
 // ---- flat path (tk_flat.hip, tk_flat_impl.h): one wave per 1024-byte region of the packed stream ----
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
-                                   hipStream_t s);
+                                   uint32_t* flags, uint32_t* holes, uint32_t* counters16, hipStream_t s);
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
 hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
 // doc_info: [n_docs] 16-byte records (TkFlatDocInfo, tk_flat.hip) written by counts, read by assemble
@@ -35,7 +35,7 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
                                  uint32_t extra, uint32_t* counts, void* doc_info, int final_pass, uint32_t* n_flagged, hipStream_t s);
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
-                                   uint32_t eos_id, int add_bos, int add_eos, hipStream_t s);
+                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, hipStream_t s);
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
 
 // ---- decode path (tk_decode.hip) ----

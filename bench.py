@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--host-steps", type=int, default=3, help="host-to-host leg (row f-4): timed passes, 0 = skip")
     ap.add_argument("--decode-steps", type=int, default=5, help="extra leg: GPU batch decode of the produced ids (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = dry run of the N>1 code path with several ranks sharing one GPU (ids staged through host)")
@@ -167,15 +168,48 @@ def main():
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
             "handed_back_docs": eng.last_stats()["handed_back"],
         }
+        if not distributed:
+            # the ids of the last timed step, on the host (the device views die with the next call on the context)
+            h_ids = torch.as_tensor(v_ids, device="cuda").cpu().numpy().view(np.uint32)
+            h_oo = torch.as_tensor(v_oo, device="cuda").cpu().numpy().astype(np.uint64)
         if not distributed and args.decode_steps > 0:
             out["decode"] = decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream)
+        if not distributed and args.host_steps > 0:
+            out["host_to_host"] = host_leg(args, tk, eng, data, offs, h_ids, h_oo)
         if not distributed and args.cpu_passes > 0:
-            out.update(cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes))
+            out.update(cpu_baseline(args, data, offs, vocab_path, h_ids, h_oo, n_bytes))
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     tokz.close()
+
+
+def host_leg(args, tk, eng, data, offs, h_ids, h_oo):
+    """the same batch from HOST memory to ids in HOST memory (PCIe inclusive; never `value`):
+    tk_encode_batch_pipelined with pinned caller buffers (copy up / kernels / copy down overlapped, 32 MiB slices) next
+    to the plain tk_encode_batch (pageable input, one copy up, kernels, one copy down)."""
+    n_docs, n_bytes = len(offs) - 1, int(offs[-1])
+    pin_data = tk.host_empty(n_bytes, np.uint8)
+    pin_data[:] = data
+    pin_offs = tk.host_empty(n_docs + 1, np.uint64)
+    pin_offs[:] = offs
+    pin_ids = tk.host_empty(n_bytes + 2 * n_docs + 1, np.uint32)
+    pin_oo = tk.host_empty(n_docs + 1, np.uint64)
+    t_pipe = []
+    for it in range(args.host_steps + 1):
+        t0 = time.perf_counter()
+        ids, oo = eng.encode_batch_pipelined(pin_data, pin_offs, True, True, 0, pin_ids, pin_oo)
+        if it:
+            t_pipe.append(time.perf_counter() - t0)
+    exact = bool(len(ids) == len(h_ids) and np.array_equal(ids, h_ids) and np.array_equal(oo, h_oo))
+    t0 = time.perf_counter()
+    eng.encode_batch(data, offs, True, True)
+    t_plain = time.perf_counter() - t0
+    tp = float(np.median(t_pipe))
+    return {"metric": "input MB/s, host buffers in -> ids in host buffers (PCIe inclusive)", "pipelined_MBps": round(n_bytes / 1e6 / tp, 1),
+            "pipelined_ms": round(tp * 1e3, 3), "plain_tk_encode_batch_MBps": round(n_bytes / 1e6 / t_plain, 1),
+            "plain_ms": round(t_plain * 1e3, 3), "slice_bytes": 32 << 20, "buffers": "pinned (tk_host_alloc)", "bit_exact_vs_device_path": exact}
 
 
 def decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream):
@@ -199,10 +233,9 @@ def decode_leg(args, tk, eng, v_ids, v_oo, n_docs, n_bytes, d_bytes, stream):
                          "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 5)}}
 
 
-def cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes):
+def cpu_baseline(args, data, offs, vocab_path, ids, oo, n_bytes):
     """The oracle, single thread, on the same documents (the checker timed as the CPU baseline) and the
     bit-exact comparison of the GPU ids with it."""
-    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import synth_vocab as sv
     import tk_oracle
@@ -215,8 +248,6 @@ def cpu_baseline(args, data, offs, vocab_path, v_ids, v_oo, n_bytes):
         eids, eoo = orc.encode_batch(sub, sub_offs, True, True, threads=1)
     dt = (time.perf_counter() - t0) / args.cpu_passes
     cpu_mbs = int(offs[m]) / 1e6 / dt
-    ids = torch.as_tensor(v_ids, device="cuda").cpu().numpy().view(np.uint32)
-    oo = torch.as_tensor(v_oo, device="cuda").cpu().numpy().astype(np.uint64)
     exact = bool(np.array_equal(oo[:m + 1], eoo) and np.array_equal(ids[:int(oo[m])], eids))
     return {"cpu_baseline": {"value": round(cpu_mbs, 1), "unit": "MB/s", "cores": 1, "kind": "port",
                              "sample": "%d docs (%d bytes) of the same workload, %d passes of %.1f s, oracle/tk_oracle.c single thread; host has %d cores"

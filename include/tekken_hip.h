@@ -80,6 +80,22 @@ int tk_encode_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offse
                     int add_bos, int add_eos, int validate_utf8, tk_result* out);
 void tk_free_result(tk_result* r);
 
+/* Streaming / pipelined ingestion (same results as tk_encode_batch, which is what the reference's
+ * `encode` returns per document).  The batch is cut into slices of whole documents (about slice_bytes of text each,
+ * 0 = default 32 MiB) that go through a three-stage pipeline on three HIP streams: host->device copy of slice k+1, the
+ * kernels of slice k, device->host copy of the ids of slice k-1 (double-buffered device staging).  The caller owns all
+ * four host buffers; when they come from tk_host_alloc (pinned memory) every copy is an asynchronous DMA and the three
+ * stages overlap -- pageable buffers work too, at the runtime's staged-copy rate.
+ *   ids_out       capacity ids_capacity; doc_offsets[n_docs] + 2 * n_docs always suffices (a document produces at most
+ *                 one id per byte, plus BOS / EOS)
+ *   offsets_out   n_docs + 1 entries
+ * TK_ERR_INVALID_ARG if the ids do not fit (*n_ids then holds the count reached when it was noticed). */
+void* tk_host_alloc(size_t bytes);      /* pinned host memory (NULL on failure) */
+void tk_host_free(void* p);
+int tk_encode_batch_pipelined(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                              int add_bos, int add_eos, uint64_t slice_bytes, uint32_t* ids_out, uint64_t ids_capacity,
+                              uint64_t* offsets_out, uint64_t* n_ids);
+
 /* Same computation with inputs already resident in HBM (hipMalloc'ed on the context's device):
  * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64 (non-decreasing, [0] = 0, [n_docs] = n_bytes:
  * not checked on this entry).  Work is enqueued on

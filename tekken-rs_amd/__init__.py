@@ -107,6 +107,12 @@ def lib():
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    L.tk_host_alloc.restype = ctypes.c_void_p
+    L.tk_host_alloc.argtypes = [ctypes.c_size_t]
+    L.tk_host_free.argtypes = [ctypes.c_void_p]
+    L.tk_encode_batch_pipelined.restype = ctypes.c_int
+    L.tk_encode_batch_pipelined.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u32p,
+                                            ctypes.c_uint64, u64p, u64p]
     L.tk_ctx_set_special_tokens.restype = ctypes.c_int
     L.tk_ctx_set_special_tokens.argtypes = [vp, u8p, u32p, ctypes.c_uint32]
     L.tk_decode_batch.restype = ctypes.c_int
@@ -244,6 +250,26 @@ class Engine:
             raise self._err(rc)
         return _take_result(res)
 
+    def encode_batch_pipelined(self, data, offs, add_bos=True, add_eos=True, slice_bytes=0, ids_out=None, offsets_out=None):
+        """tk_encode_batch_pipelined: the batch streams through the GPU in slices (copy up / kernels / copy down overlapped).
+        data / offs / ids_out / offsets_out may be pinned arrays from `host_empty` (then every copy is an asynchronous
+        DMA); ids_out (uint32) must hold offs[-1] + 2 * n_docs ids at most.  Returns (ids view, offsets)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n_docs = len(offs) - 1
+        if ids_out is None:
+            ids_out = np.empty(int(offs[-1]) + 2 * n_docs + 1, np.uint32)
+        if offsets_out is None:
+            offsets_out = np.empty(n_docs + 1, np.uint64)
+        n = ctypes.c_uint64(0)
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        rc = lib().tk_encode_batch_pipelined(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), n_docs, int(add_bos),
+                                             int(add_eos), int(slice_bytes), _p(ids_out, ctypes.c_uint32), len(ids_out),
+                                             _p(offsets_out, ctypes.c_uint64), ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        return ids_out[:int(n.value)], offsets_out
+
     def encode_docs(self, docs, add_bos=True, add_eos=True, validate_utf8=False):
         data, offs = pack_docs(docs)
         ids, oo = self.encode_batch(data, offs, add_bos, add_eos, validate_utf8)
@@ -340,6 +366,30 @@ class Engine:
             a, b = int(offs[d]), int(offs[d + 1])
             res.append(np.nonzero(out[a:b])[0].tolist())
         return res
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            lib().tk_host_free(ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def host_empty(n, dtype):
+    """numpy array of n elements in PINNED host memory (tk_host_alloc): the buffers tk_encode_batch_pipelined wants."""
+    dt = np.dtype(dtype)
+    nbytes = max(int(n) * dt.itemsize, 1)
+    ptr = lib().tk_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError("tk_host_alloc(%d) failed" % nbytes)
+    owner = _Pinned(ptr)
+    raw = (ctypes.c_uint8 * nbytes).from_address(ptr)
+    raw._tk_owner = owner                  # the array keeps `raw` alive (its base), `raw` keeps the allocation alive
+    return np.frombuffer(raw, dtype=dt, count=int(n))
 
 
 class Tekkenizer:

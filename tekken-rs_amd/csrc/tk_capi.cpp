@@ -66,6 +66,12 @@ struct tk_ctx {
     uint64_t n_long_docs = 0;
     uint32_t* dbg_mark = nullptr;  // pinned host memory, only with TK_DEBUG_MARKS
     uint32_t* h_pin = nullptr;     // pinned host words: the per-batch device counters land here with ONE copy
+    // pipelined ingestion (tk_encode_batch_pipelined): copy streams, events, the second set of staging buffers
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    DevBuf in_bytes2, in_offs2, out_ids2, out_offs2;
+    uint64_t* h_offs_stage[2] = {nullptr, nullptr};   // pinned: slice-relative document offsets going up
+    uint64_t h_offs_cap = 0;
 };
 
 #define TK_HIP(ctx, call)                                                                          \
@@ -180,6 +186,15 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    DevBuf* pbufs[] = {&c->in_bytes2, &c->in_offs2, &c->out_ids2, &c->out_offs2};
+    for (DevBuf* b : pbufs) b->release();
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+        if (c->h_offs_stage[i]) (void)hipHostFree(c->h_offs_stage[i]);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     delete c;
 }
 
@@ -504,6 +519,134 @@ extern "C" int tk_encode_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* 
     out->offsets = h_offs;
     out->n_ids = n_ids;
     out->n_docs = n_docs;
+    return TK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pipelined ingestion (row f-4)
+// ------------------------------------------------------------------------------------------
+extern "C" void* tk_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void tk_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int tk_encode_batch_pipelined(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
+                                         int add_bos, int add_eos, uint64_t slice_bytes, uint32_t* ids_out, uint64_t ids_capacity,
+                                         uint64_t* offsets_out, uint64_t* n_ids_out) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!doc_offsets || !offsets_out || !n_ids_out || (!ids_out && ids_capacity) || (!bytes && doc_offsets[n_docs])) {
+        c->err = "null argument";
+        return TK_ERR_INVALID_ARG;
+    }
+    if (n_docs >= 0xFFFFFFF0ull) { c->err = "too many documents in one batch"; return TK_ERR_INVALID_ARG; }
+    *n_ids_out = 0;
+    int rc = check_offsets(c, doc_offsets, n_docs);
+    if (rc != TK_OK) return rc;
+    TK_HIP(c, hipSetDevice(c->device));
+    if (!c->s_in) {
+        TK_HIP(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        TK_HIP(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            TK_HIP(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            TK_HIP(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    if (slice_bytes == 0) slice_bytes = 32ull << 20;
+    // slices of whole documents: [cut[k], cut[k + 1])
+    std::vector<uint64_t> cut(1, 0);
+    uint64_t max_bytes = 0, max_docs = 0;
+    for (uint64_t d = 0; d < n_docs;) {
+        const uint64_t b0 = doc_offsets[d];
+        uint64_t e = d + 1;                               // at least one document per slice, however long it is
+        while (e < n_docs && doc_offsets[e + 1] - b0 <= slice_bytes && e - d < (1ull << 22)) ++e;
+        cut.push_back(e);
+        if (doc_offsets[e] - b0 > max_bytes) max_bytes = doc_offsets[e] - b0;
+        if (e - d > max_docs) max_docs = e - d;
+        d = e;
+    }
+    const size_t n_slices = cut.size() - 1;
+    offsets_out[0] = 0;
+    if (n_slices == 0) return TK_OK;
+    // staging: two input sets, two output sets (run_pipeline writes c->out_ids / c->out_offs: the sets are swapped per slice)
+    DevBuf* inb[2] = {&c->in_bytes, &c->in_bytes2};
+    DevBuf* ino[2] = {&c->in_offs, &c->in_offs2};
+    for (int i = 0; i < 2; ++i) {
+        TK_HIP(c, inb[i]->reserve(max_bytes + 64));
+        TK_HIP(c, ino[i]->reserve((max_docs + 1) * 8));
+    }
+    TK_HIP(c, c->out_ids.reserve((max_bytes + 2 * max_docs + 64) * 4));
+    TK_HIP(c, c->out_ids2.reserve((max_bytes + 2 * max_docs + 64) * 4));
+    TK_HIP(c, c->out_offs.reserve((max_docs + 1) * 8));
+    TK_HIP(c, c->out_offs2.reserve((max_docs + 1) * 8));
+    if (c->h_offs_cap < max_docs + 1) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_offs_stage[i]) (void)hipHostFree(c->h_offs_stage[i]);
+            c->h_offs_stage[i] = nullptr;
+            TK_HIP(c, hipHostMalloc((void**)&c->h_offs_stage[i], (max_docs + 1) * 8, hipHostMallocDefault));
+        }
+        c->h_offs_cap = max_docs + 1;
+    }
+    auto upload_slice = [&](size_t k) -> int {            // host -> device of slice k on the input stream
+        const int b = (int)(k & 1);
+        const uint64_t d0 = cut[k], d1 = cut[k + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
+        uint64_t* ho = c->h_offs_stage[b];
+        for (uint64_t d = d0; d <= d1; ++d) ho[d - d0] = doc_offsets[d] - b0;
+        if (nb) TK_HIP(c, hipMemcpyAsync(inb[b]->p, bytes + b0, nb, hipMemcpyHostToDevice, c->s_in));
+        TK_HIP(c, hipMemcpyAsync(ino[b]->p, ho, (d1 - d0 + 1) * 8, hipMemcpyHostToDevice, c->s_in));
+        TK_HIP(c, hipEventRecord(c->ev_in[b], c->s_in));
+        return TK_OK;
+    };
+    uint64_t id_base = 0;
+    std::vector<uint64_t> slice_ids(n_slices, 0);
+    float pipe_ms = 0.f, enc_ms = 0.f;
+    uint64_t flagged = 0, longd = 0;
+    // the offsets staging of slice k is rewritten by upload_slice(k + 2): that copy must have been consumed -- it has, the
+    // kernels of slice k (which waited for it) are complete when run_pipeline returns
+    if ((rc = upload_slice(0)) != TK_OK) return rc;
+    for (size_t k = 0; k < n_slices; ++k) {
+        const int b = (int)(k & 1);
+        if (k + 1 < n_slices && (rc = upload_slice(k + 1)) != TK_OK) break;
+        const uint64_t d0 = cut[k], d1 = cut[k + 1], nb = doc_offsets[d1] - doc_offsets[d0];
+        TK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
+        if (k >= 2) TK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_out[b], 0));   // the ids of slice k - 2 have left this output set
+        uint64_t n_ids = 0;
+        rc = run_pipeline(c, (const uint8_t*)inb[b]->p, (const uint64_t*)ino[b]->p, d1 - d0, nb, add_bos, add_eos, c->stream, &n_ids);
+        if (rc != TK_OK) break;
+        pipe_ms += c->pipeline_ms; enc_ms += c->encode_ms; flagged += c->n_flagged; longd += c->n_long_docs;
+        slice_ids[k] = n_ids;
+        if (id_base + n_ids > ids_capacity) {
+            *n_ids_out = id_base + n_ids;
+            c->err = "ids_out is too small";
+            rc = TK_ERR_INVALID_ARG;
+            break;
+        }
+        // device -> host on the output stream (run_pipeline returned after its stream drained: the ids are complete)
+        if (n_ids) TK_HIP(c, hipMemcpyAsync(ids_out + id_base, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost, c->s_out));
+        TK_HIP(c, hipMemcpyAsync(offsets_out + d0 + 1, (const uint64_t*)c->out_offs.p + 1, (d1 - d0) * 8, hipMemcpyDeviceToHost, c->s_out));
+        TK_HIP(c, hipEventRecord(c->ev_out[b], c->s_out));
+        std::swap(c->out_ids, c->out_ids2);
+        std::swap(c->out_offs, c->out_offs2);
+        id_base += n_ids;
+    }
+    // drain the copy streams whatever happened (buffers must not be in flight when the call returns)
+    (void)hipStreamSynchronize(c->s_in);
+    hipError_t e = hipStreamSynchronize(c->s_out);
+    if (rc != TK_OK) return rc;
+    if (e != hipSuccess) { c->err = std::string("result copy failed: ") + hipGetErrorString(e); return TK_ERR_RUNTIME; }
+    // slice-relative id offsets -> batch offsets
+    uint64_t base = 0;
+    for (size_t k = 0; k < n_slices; ++k) {
+        if (base)
+            for (uint64_t d = cut[k] + 1; d <= cut[k + 1]; ++d) offsets_out[d] += base;
+        base += slice_ids[k];
+    }
+    c->pipeline_ms = pipe_ms; c->encode_ms = enc_ms; c->n_flagged = flagged; c->n_long_docs = longd;
+    *n_ids_out = id_base;
     return TK_OK;
 }
 

@@ -322,3 +322,37 @@ def test_table_cache_context(tk, bench_vocab, tmp_path, monkeypatch):
     check_batch(e3, orc, data, offs)
     e3.close()
     assert open(files[0], "rb").read() == raw
+
+
+def test_pipelined_ingestion(tk, eng_small, test_vocab):
+    """Row f-4: the streaming entry (slices of whole documents, copy up / kernels / copy down overlapped, caller-owned
+    pinned buffers) returns exactly what tk_encode_batch returns -- for slices of one document, slices larger than the
+    batch, documents longer than a slice, empty documents at slice edges, and every BOS / EOS combination."""
+    import random
+    rng = random.Random(11)
+    docs = helpers.mixed_docs(300, 50, 400, max_len=30000) + [b""] * 5 + helpers.random_unicode_docs(200) + [b"", b"x", b""]
+    rng.shuffle(docs)
+    data, offs = tk.pack_docs(docs)
+    pin_data = tk.host_empty(len(data), np.uint8)
+    pin_data[:] = data
+    pin_offs = tk.host_empty(len(offs), np.uint64)
+    pin_offs[:] = offs
+    pin_ids = tk.host_empty(len(data) + 2 * len(docs) + 1, np.uint32)
+    pin_oo = tk.host_empty(len(offs), np.uint64)
+    for bos, eos in ((True, True), (False, False), (True, False)):
+        exp_ids, exp_oo = eng_small.encode_batch(data, offs, bos, eos)
+        for sl in (1, 700, 4096, 100000, 0):
+            ids, oo = eng_small.encode_batch_pipelined(pin_data, pin_offs, bos, eos, slice_bytes=sl, ids_out=pin_ids, offsets_out=pin_oo)
+            assert np.array_equal(oo, exp_oo), (bos, eos, sl)
+            assert np.array_equal(ids, exp_ids), (bos, eos, sl)
+        ids, oo = eng_small.encode_batch_pipelined(data, offs, bos, eos, slice_bytes=5000)      # pageable buffers
+        assert np.array_equal(oo, exp_oo) and np.array_equal(ids, exp_ids)
+    # no documents / only empty documents
+    ids, oo = eng_small.encode_batch_pipelined(np.zeros(0, np.uint8), np.zeros(1, np.uint64), True, True)
+    assert len(ids) == 0 and oo.tolist() == [0]
+    ids, oo = eng_small.encode_batch_pipelined(np.zeros(0, np.uint8), np.zeros(4, np.uint64), True, True)
+    assert ids.tolist() == [test_vocab["bos"], test_vocab["eos"]] * 3 and oo.tolist() == [0, 2, 4, 6]
+    # an output buffer that is too small is refused, not overrun
+    small = np.empty(10, np.uint32)
+    with pytest.raises(tk.TokenizerError):
+        eng_small.encode_batch_pipelined(data, offs, True, True, slice_bytes=4096, ids_out=small)

@@ -356,3 +356,22 @@ def test_pipelined_ingestion(tk, eng_small, test_vocab):
     small = np.empty(10, np.uint32)
     with pytest.raises(tk.TokenizerError):
         eng_small.encode_batch_pipelined(data, offs, True, True, slice_bytes=4096, ids_out=small)
+
+
+def test_key_hash_fallback_kernel(tk, test_vocab):
+    """The kernel instantiation for tables built with the strong key hash (mode 1; tests/test_flat_path.py builds the
+    same three colliding 12-byte tokens on the emulator): lookups stay exact for those tokens and for everything else."""
+    import struct
+
+    def rotl(x, r):
+        return ((x << r) | (x >> (32 - r))) & 0xFFFFFFFF
+    x, k1 = 0x6C6C6568, 0x6F77206F
+    extra = [struct.pack("<III", x ^ rotl(k2, 13), k1, k2) for k2 in (0x61616161, 0x62626262, 0x63636363)]
+    toks = list(test_vocab["tokens"]) + [t for t in extra if t not in test_vocab["tokens"]]
+    v = dict(test_vocab, tokens=toks)
+    orc = helpers.oracle_for(v)
+    e = tk.Engine(toks, v["num_special"], v["bos"], v["eos"], device=0)
+    docs = [b"hello world aaaa", extra[0] + b" " + extra[1], extra[2], b"x" + extra[0][1:]] + helpers.mixed_docs(150, 40, 300, max_len=20000) \
+        + helpers.random_unicode_docs(100)
+    assert e.encode_docs(docs, True, True) == [orc.encode(d, True, True) for d in docs]
+    e.close()

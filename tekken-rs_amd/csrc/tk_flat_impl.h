@@ -311,19 +311,25 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
         uint32_t* cl = lds + TKF_L_CL;
         cl[lane] = 0u; cl[64 + lane] = 0u; cl[128 + lane] = 0u;
+        if (lane == 0) {
+            // the code point of a lead byte in the region's last three bytes ends beyond it: the pad word takes the real bytes
+            uint32_t pad = 0u;
+            for (int k = 0; k < 4; ++k)
+                if (r1 + k < n) pad |= (uint32_t)a.bytes[r1 + k] << (8 * k);
+            lds[TKF_L_TXT + 256] = pad;
+        }
         wv_lds_sync();
         bool nmb = false;
         uint32_t w = m.LEAD;
-        const int64_t g = r0 + 16 * lane;
         while (wv_ballot(w != 0u)) {
             if (w) {
                 const int i = __builtin_ctz(w);
                 w &= w - 1u;
-                const int64_t q = g + i;         // a lead byte is a real byte: 0 <= q < n
-                const uint32_t b0 = a.bytes[q];
-                const uint32_t b1 = q + 1 < n ? (uint32_t)a.bytes[q + 1] : 0u;
-                const uint32_t b2 = q + 2 < n ? (uint32_t)a.bytes[q + 2] : 0u;
-                const uint32_t b3 = q + 3 < n ? (uint32_t)a.bytes[q + 3] : 0u;
+                // the char's (up to) four bytes from the LDS copy of the region (bytes outside [0, n) are zero there)
+                const uint32_t p = 16u * (uint32_t)lane + (uint32_t)i;
+                const uint32_t* tw = lds + TKF_L_TXT + (p >> 2);
+                const uint32_t v4 = wv_alignbyte(tw[1], tw[0], p & 3u);
+                const uint32_t b0 = v4 & 0xFFu, b1 = (v4 >> 8) & 0xFFu, b2 = (v4 >> 16) & 0xFFu, b3 = v4 >> 24;
                 uint32_t cp = 0xFFFFFFFFu, clen = 1;
                 if (b0 < 0xE0u) {
                     if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }

@@ -20,7 +20,11 @@
 
 #define TKF_BLOCK 256
 #ifndef TKF_OCC
+#if TKF_W == 32
+#define TKF_OCC __attribute__((amdgpu_waves_per_eu(7, 7)))  /* the LDS slices of 28 waves fill the CU: 7 waves per SIMD, <= 72 VGPRs */
+#else
 #define TKF_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))  /* 8 waves per SIMD: <= 64 VGPRs */
+#endif
 #endif
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
@@ -320,14 +324,16 @@ hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, ui
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     uint64_t blocks = (a.n_chunks + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
-    // persistent waves, chunks strided over them: exactly the blocks that are resident at once (8 per CU at 8 waves per SIMD),
-    // so that no partially filled last round of blocks trails behind
+    // persistent waves, chunks strided over them: exactly the blocks that are resident at once, so that no partially
+    // filled last round of blocks trails behind
     static uint64_t cap = 0;
     if (cap == 0) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        cap = (uint64_t)cus * 8;
+        int per_cu = 0;   // resident blocks per CU: 8 (16 bytes per lane, 8 waves per SIMD) or 7 (32 bytes per lane: LDS)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tk_flat_kernel, TKF_BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        cap = (uint64_t)cus * (uint64_t)per_cu;
         if (const char* e = getenv("TK_FLAT_BLOCKS")) cap = (uint64_t)atoll(e);
         if (cap == 0) cap = 1280;
     }

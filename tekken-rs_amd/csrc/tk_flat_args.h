@@ -5,17 +5,30 @@
 
 #include "tk_tables.h"
 
-#define TKF_REGION 1024                              /* bytes loaded per chunk: 64 lanes x 16 bytes */
+#ifndef TKF_W
+#define TKF_W 32                                     /* bytes per lane = bits of a lane-layout mask word: 16 or 32 */
+#endif
+#define TKF_REGION (64 * TKF_W)                      /* bytes loaded per chunk: 64 lanes x TKF_W bytes */
 #define TKF_HL 32                                    /* left halo (look-behind context) */
 #define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
-#define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* 928 bytes committed per chunk */
+#define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* bytes committed per chunk: 928 / 1952 */
 #define TKF_STRIDE (TKF_COMMIT + 64)                 /* id slots per chunk: a piece may reach 63 bytes past the commit range */
-/* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): a chunk commits 928 bytes */
+/* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes) */
 #define TKF_MISSOFF0 0u
-#define TKF_MISSOFF1 464u                            /* 928 / 2 */
-#define TKF_MISSOFF2 568u                            /* + ceil(928 / 9) */
-#define TKF_MISSOFF3 624u                            /* + ceil(928 / 17) */
-#define TKF_MISSCAP 656u                             /* + ceil(928 / 33), rounded up */
+#define TKF_MISSOFF1 (TKF_COMMIT / 2u)                              /* at most COMMIT / 2 pieces of >= 2 bytes */
+#define TKF_MISSOFF2 (TKF_MISSOFF1 + (TKF_COMMIT + 8u) / 9u)
+#define TKF_MISSOFF3 (TKF_MISSOFF2 + (TKF_COMMIT + 16u) / 17u)
+#define TKF_MISSCAP ((TKF_MISSOFF3 + (TKF_COMMIT + 32u) / 33u + 7u) & ~7u)
+/* queue record: position in the region | length << POSBITS | id slot << (POSBITS + 7) */
+#if TKF_W == 32
+#define TKF_POSBITS 11
+#else
+#define TKF_POSBITS 10
+#endif
+#define TKF_REC(pos, len, slot) ((pos) | ((len) << TKF_POSBITS) | ((slot) << (TKF_POSBITS + 7)))
+#define TKF_REC_POS(rec) ((rec) & ((1u << TKF_POSBITS) - 1u))
+#define TKF_REC_LEN(rec) (((rec) >> TKF_POSBITS) & 127u)
+#define TKF_REC_SLOT(rec) ((rec) >> (TKF_POSBITS + 7))
 #define TKF_HOLE 0xFFFFFFFFu                         /* id slot reserved by a missed piece and not used */
 
 struct TkFlatArgs {
@@ -26,7 +39,7 @@ struct TkFlatArgs {
     uint32_t* tmp;               // [n_chunks * TKF_STRIDE] chunk-dense ids
     uint32_t* kcount;            // [n_chunks] id slots of the chunk (holes included)
     uint32_t* lstart;            // [n_docs] id slots of the chunk before the document's first byte
-    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: pos | len << 10 | slot << 17,
+    uint32_t* miss_list;         // [n_chunks * TKF_MISSCAP] per chunk, the pieces that missed the vocabulary: TKF_REC(pos, len, slot),
                                  // sub-queue of length class k at TKF_MISSOFFk
     uint32_t* miss_count;        // [4 * n_chunks] class-major: queued pieces of class k of chunk c at [k * n_chunks + c]
     const uint64_t* miss_prefix; // [4 * n_chunks + 1] exclusive prefix sums of miss_count (the merge kernels' item order)

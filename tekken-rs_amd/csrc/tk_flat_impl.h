@@ -35,12 +35,28 @@
 #include "tk_encode_impl.h"
 #include "tk_flat_args.h"
 
-#define TKF_W 16
+#if TKF_W == 32
+#define TKF_WM 0xFFFFFFFFu
+#define TKF_LOGW 5
+#define TKF_TOPBIT 0x80000000u
+#else
 #define TKF_WM 0xFFFFu
+#define TKF_LOGW 4
+#define TKF_TOPBIT 0x8000u
+#endif
+#define TKF_NHL (TKF_HL / TKF_W)                     /* lanes of the left halo: 2 / 1 */
+/* entries of the LDS piece list.  16 bytes per lane: every byte could start a piece.  32 bytes per lane: a chunk with
+   more pieces than this (an average of under two bytes per piece over 2 KB) is handed back as a whole */
+#if TKF_W == 32
+#define TKF_LISTCAP 1056
+#else
+#define TKF_LISTCAP (TKF_REGION + 8)
+#endif
+#define TKF_MAXPIECES (TKF_LISTCAP - 2)              /* + the sentinel */
 
 // LDS words of one wave
 #define TKF_L_LIST 0                                /* u16 [REGION + 4] piece positions, then the id slot of every piece */
-#define TKF_L_DS (TKF_L_LIST + TKF_REGION / 2 + 4)  /* [64] document-start mask words */
+#define TKF_L_DS (TKF_L_LIST + TKF_LISTCAP / 2)      /* [64] document-start mask words */
 #define TKF_L_PS (TKF_L_DS + 64)                    /* [64] owned piece-start mask words */
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
@@ -48,8 +64,8 @@
 #define TKF_L_CL TKF_L_LIST                          /* [3 * 64] classes L, N, S of the multi-byte code points (step 1 only: shares the
                                                         words of the piece list, which is built in step 5) */
 #define TKF_L_KM (TKF_L_BPFX + 64)                  /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
-#define TKF_L_TXT (TKF_L_KM + 17 * 4)                /* [256 + 4] the region's bytes: a piece's 16 bytes are read from here */
-#define TKF_L_CONST (TKF_L_TXT + 256 + 4)              /* [8] wave-uniform constants of the probe: KEY8 mask, KEY16 mask, KEY8 base, KEY16 base.
+#define TKF_L_TXT (TKF_L_KM + 17 * 4)                /* [REGION / 4 + 4] the region's bytes: a piece's 16 bytes are read from here */
+#define TKF_L_CONST (TKF_L_TXT + TKF_REGION / 4 + 4)              /* [8] wave-uniform constants of the probe: KEY8 mask, KEY16 mask, KEY8 base, KEY16 base.
                                                         The kernel is out of scalar registers (spilled SGPRs come back through
                                                         v_readlane, a VALU slot each, and VALU issue is what bounds it); an LDS
                                                         broadcast read costs an LDS slot, of which it has plenty */
@@ -61,23 +77,29 @@
 // ------------------------------------------------------------------------------------------
 // (own word above / below the neighbour's in one register, then ONE bit-field extract: 3 VALU per shift, and the
 // combined word is shared by shifts of the same mask)
+#if TKF_W == 32
+// (one funnel shift over {own word : neighbour's word}: DPP move + v_alignbit)
+TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return (uint32_t)((((uint64_t)x << 32) | (uint64_t)wv_dn1(x)) >> (32 - k)); }  // 1 <= k <= 31
+TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return (uint32_t)((((uint64_t)wv_up1(x) << 32) | (uint64_t)x) >> k); }
+#else
 TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return (((x << TKF_W) | wv_dn1(x)) >> (TKF_W - k)) & TKF_WM; }  // 1 <= k <= 16
 TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return (((wv_up1(x) << TKF_W) | x) >> k) & TKF_WM; }
+#endif
 TK_DEV uint32_t tkf_shl_any(uint32_t x, int k, int lane) {
-    const int q = k >> 4, r = k & 15;
+    const int q = k >> TKF_LOGW, r = k & (TKF_W - 1);
     const int s1 = lane - q, s2 = lane - q - 1;
     uint32_t v1 = wv_shfl(x, s1 & 63), v2 = wv_shfl(x, s2 & 63);
     if (s1 < 0) v1 = 0;
     if (s2 < 0) v2 = 0;
-    return ((v1 << r) | (v2 >> (TKF_W - r))) & TKF_WM;
+    return (uint32_t)((((uint64_t)v1 << TKF_W) | (uint64_t)v2) >> (TKF_W - r)) & TKF_WM;
 }
 TK_DEV uint32_t tkf_shr_any(uint32_t x, int k, int lane) {
-    const int q = k >> 4, r = k & 15;
+    const int q = k >> TKF_LOGW, r = k & (TKF_W - 1);
     const int s1 = lane + q, s2 = lane + q + 1;
     uint32_t v1 = wv_shfl(x, s1 & 63), v2 = wv_shfl(x, s2 & 63);
     if (s1 > 63) v1 = 0;
     if (s2 > 63) v2 = 0;
-    return ((v1 >> r) | (v2 << (TKF_W - r))) & TKF_WM;
+    return (uint32_t)((((uint64_t)v2 << TKF_W) | (uint64_t)v1) >> r) & TKF_WM;
 }
 TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
 
@@ -85,8 +107,12 @@ TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
 // (G = lanes that generate a carry, P = lanes that would pass one on) hands every lane its carry-in
 TK_DEV uint32_t tkf_add(uint32_t a, uint32_t b) {
     const uint32_t t = a + b;
+#if TKF_W == 32
+    const uint64_t G = wv_ballot(t < a);                  // the word itself overflowed
+#else
     const uint64_t G = wv_ballot((t >> TKF_W) != 0u);
-    const uint64_t P = wv_ballot(t == TKF_WM);
+#endif
+    const uint64_t P = wv_ballot((t & TKF_WM) == TKF_WM);
     const uint64_t x = G | P;
     const uint64_t cin = (x + G) ^ x ^ G;  // carry into lane l = bit l
     return (t + (wv_inverse_ballot(cin) ? 1u : 0u)) & TKF_WM;
@@ -134,10 +160,25 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     uint32_t a_lo = x[0], a_hi = x[1], b_lo = x[2], b_hi = x[3];
     tkf_transpose8(a_lo, a_hi);
     tkf_transpose8(b_lo, b_hi);
+#if TKF_W == 32
+    // four groups of 8 bytes: plane p = byte p of the four transposed groups -- a 4 x 4 byte transpose (v_perm), twice
+    uint32_t c_lo = x[4], c_hi = x[5], d_lo = x[6], d_hi = x[7];
+    tkf_transpose8(c_lo, c_hi);
+    tkf_transpose8(d_lo, d_hi);
+    const uint32_t u0 = wv_perm(b_lo, a_lo, 0x05010400u), u1 = wv_perm(b_lo, a_lo, 0x07030602u);   // {a0 b0 a1 b1}, {a2 b2 a3 b3}
+    const uint32_t v0 = wv_perm(d_lo, c_lo, 0x05010400u), v1 = wv_perm(d_lo, c_lo, 0x07030602u);
+    const uint32_t p0 = wv_perm(v0, u0, 0x05040100u), p1 = wv_perm(v0, u0, 0x07060302u);
+    const uint32_t p2 = wv_perm(v1, u1, 0x05040100u), p3 = wv_perm(v1, u1, 0x07060302u);
+    const uint32_t u2 = wv_perm(b_hi, a_hi, 0x05010400u), u3 = wv_perm(b_hi, a_hi, 0x07030602u);
+    const uint32_t v2 = wv_perm(d_hi, c_hi, 0x05010400u), v3 = wv_perm(d_hi, c_hi, 0x07030602u);
+    const uint32_t p4 = wv_perm(v2, u2, 0x05040100u), p5 = wv_perm(v2, u2, 0x07060302u);
+    const uint32_t p6 = wv_perm(v3, u3, 0x05040100u), p7 = wv_perm(v3, u3, 0x07060302u);
+#else
     const uint32_t p0 = wv_perm(b_lo, a_lo, 0x07030400u) & 0xFFFFu, p1 = wv_perm(b_lo, a_lo, 0x07030501u) & 0xFFFFu;
     const uint32_t p2 = wv_perm(b_lo, a_lo, 0x07030602u) & 0xFFFFu, p3 = wv_perm(b_lo, a_lo, 0x07030703u) & 0xFFFFu;
     const uint32_t p4 = wv_perm(b_hi, a_hi, 0x07030400u) & 0xFFFFu, p5 = wv_perm(b_hi, a_hi, 0x07030501u) & 0xFFFFu;
     const uint32_t p6 = wv_perm(b_hi, a_hi, 0x07030602u) & 0xFFFFu, p7 = wv_perm(b_hi, a_hi, 0x07030703u) & 0xFFFFu;
+#endif
     TkfClass c;
     const uint32_t hz = TKF_WM & ~(p7 | p6 | p5 | p4);            // high nibble 0
     const uint32_t pre = p6 & ~p7;                                // 0x40..0x7F: letters differ in bit 5 only
@@ -168,7 +209,7 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
 // ------------------------------------------------------------------------------------------
 TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SPR_out, uint32_t* cont_out) {
     const uint32_t nDS = ~DS & TKF_WM;
-    const uint32_t DE = tkf_shr(DS, 1) | (lane == 63 ? 0x8000u : 0u);
+    const uint32_t DE = tkf_shr(DS, 1) | (lane == 63 ? TKF_TOPBIT : 0u);
     const uint32_t nDE = ~DE & TKF_WM;
 #define P1(x) (tkf_shl((x), 1) & nDS)
 #define N1(x) (tkf_shr((x), 1) & nDE)
@@ -287,23 +328,24 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     const int ca = TKF_HL, cb = (int)(c1 - r0);  // commit range in region coordinates
     uint16_t* list = reinterpret_cast<uint16_t*>(lds + TKF_L_LIST);
 
-    // ---- 1. load 16 bytes per lane, classify ---------------------------------------------------
-    uint32_t x[4] = {0u, 0u, 0u, 0u};
+    // ---- 1. load TKF_W bytes per lane, classify ---------------------------------------------------
+    uint32_t x[TKF_W / 4];
+    for (int k = 0; k < TKF_W / 4; ++k) x[k] = 0u;
     {
-        const int64_t g = r0 + 16 * lane;
-        if (g >= 0 && g + 16 <= n) {
-            wv_load16(a.bytes + g, x);
-        } else if (g + 16 > 0 && g < n) {
-            for (int k = 0; k < 16; ++k) {
+        const int64_t g = r0 + TKF_W * lane;
+        if (g >= 0 && g + TKF_W <= n) {
+            for (int k = 0; k < TKF_W / 16; ++k) wv_load16(a.bytes + g + 16 * k, x + 4 * k);
+        } else if (g + TKF_W > 0 && g < n) {
+            for (int k = 0; k < TKF_W; ++k) {
                 const int64_t q = g + k;
                 if (q >= 0 && q < n) x[k >> 2] |= (uint32_t)a.bytes[q] << (8 * (k & 3));
             }
         }
     }
     {
-        uint32_t* txt = lds + TKF_L_TXT + 4 * lane;   // bytes outside [0, n) are zero
-        txt[0] = x[0]; txt[1] = x[1]; txt[2] = x[2]; txt[3] = x[3];
-        if (lane == 0) { lds[TKF_L_TXT + 256] = 0u; lds[TKF_L_TXT + 257] = 0u; lds[TKF_L_TXT + 258] = 0u; lds[TKF_L_TXT + 259] = 0u; }
+        uint32_t* txt = lds + TKF_L_TXT + (TKF_W / 4) * lane;   // bytes outside [0, n) are zero
+        for (int k = 0; k < TKF_W / 4; ++k) txt[k] = x[k];
+        if (lane == 0) for (int k = 0; k < 4; ++k) lds[TKF_L_TXT + TKF_REGION / 4 + k] = 0u;
     }
     TkfClass m = tkf_classify(x);
     if (tkf_any(m.HI)) {
@@ -316,7 +358,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             uint32_t pad = 0u;
             for (int k = 0; k < 4; ++k)
                 if (r1 + k < n) pad |= (uint32_t)a.bytes[r1 + k] << (8 * k);
-            lds[TKF_L_TXT + 256] = pad;
+            lds[TKF_L_TXT + TKF_REGION / 4] = pad;
         }
         wv_lds_sync();
         bool nmb = false;
@@ -326,7 +368,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 const int i = __builtin_ctz(w);
                 w &= w - 1u;
                 // the char's (up to) four bytes from the LDS copy of the region (bytes outside [0, n) are zero there)
-                const uint32_t p = 16u * (uint32_t)lane + (uint32_t)i;
+                const uint32_t p = (uint32_t)TKF_W * (uint32_t)lane + (uint32_t)i;
                 const uint32_t* tw = lds + TKF_L_TXT + (p >> 2);
                 const uint32_t v4 = wv_alignbyte(tw[1], tw[0], p & 3u);
                 const uint32_t b0 = v4 & 0xFFu, b1 = (v4 >> 8) & 0xFFu, b2 = (v4 >> 16) & 0xFFu, b3 = v4 >> 24;
@@ -344,9 +386,9 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 }
                 const uint32_t cls = cp != 0xFFFFFFFFu ? tk_uc_class(t, cp) : TK_CLS_O;
                 if (cls != TK_CLS_O) {
-                    const uint32_t bits = ((1u << clen) - 1u) << i;   // up to bit 18
-                    wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, bits & TKF_WM);
-                    if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, bits >> TKF_W);
+                    const uint64_t bits = (uint64_t)((1u << clen) - 1u) << i;   // may reach into the next lane's word
+                    wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
+                    if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
                     if (cls == TK_CLS_N) nmb = true;
                 }
             }
@@ -380,7 +422,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             int64_t s = INT64_MAX;
             if (d <= a.n_docs) s = (int64_t)a.doc_offs[d];
             const bool in = s < r1;
-            if (in) wv_lds_or(lds + TKF_L_DS + ((s - r0) >> 4), 1u << ((s - r0) & 15));
+            if (in) wv_lds_or(lds + TKF_L_DS + ((s - r0) >> TKF_LOGW), 1u << ((s - r0) & (TKF_W - 1)));
             if (s == r1) starts_at_r1 = true;
             if (wv_ballot(in) != ~0ull) break;
         }
@@ -400,46 +442,55 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         return;
     }
     // bits of the commit range [ca, cb): whole lanes 2..59 for every chunk but the last one of the stream
-    uint32_t commit_mask = (uint32_t)(lane - TKF_HL / 16) < (uint32_t)(TKF_COMMIT / 16) ? TKF_WM : 0u;
+    uint32_t commit_mask = (uint32_t)(lane - TKF_NHL) < (uint32_t)(TKF_COMMIT / TKF_W) ? TKF_WM : 0u;
     if (cb != TKF_HL + TKF_COMMIT)
-        commit_mask = (tkf_lowmask32(cb - 16 * lane < 0 ? 0 : cb - 16 * lane) & ~tkf_lowmask32(ca - 16 * lane < 0 ? 0 : ca - 16 * lane)) & TKF_WM;
+        commit_mask = (tkf_lowmask32(cb - TKF_W * lane < 0 ? 0 : cb - TKF_W * lane) & ~tkf_lowmask32(ca - TKF_W * lane < 0 ? 0 : ca - TKF_W * lane)) & TKF_WM;
     if (DBG && a.dbg_starts) {
-        for (int k = 0; k < 16; ++k)
-            if ((commit_mask >> k) & 1u) a.dbg_starts[r0 + 16 * lane + k] = (PS >> k) & 1u;
+        for (int k = 0; k < TKF_W; ++k)
+            if ((commit_mask >> k) & 1u) a.dbg_starts[r0 + TKF_W * lane + k] = (PS >> k) & 1u;
     }
 
     // ---- 4. positions that make their document fall back ---------------------------------------
     uint32_t BAD = 0;
     {
         // (A) a digit / CR-LF run that comes from below the region and covers the whole left halo
-        const uint32_t d0 = wv_readlane(DS, 0), d1 = wv_readlane(DS, 1);
         // (the region may begin inside a code point: its leading continuation bytes have no class and count as part of the run)
+#if TKF_NHL == 2
+        const uint32_t d0 = wv_readlane(DS, 0) | wv_readlane(DS, 1);
         const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0), n1 = wv_readlane(m.N, 1);
         const uint32_t l0 = wv_readlane(m.NL, 0), l1 = wv_readlane(m.NL, 1);
         const bool covered = (n0 == TKF_WM && n1 == TKF_WM) || (l0 == TKF_WM && l1 == TKF_WM);
-        if (r0 > 0 && d0 == 0u && d1 == 0u && covered && lane == 2) BAD |= 1u;
+#else
+        const uint32_t d0 = wv_readlane(DS, 0);
+        const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0);
+        const uint32_t l0 = wv_readlane(m.NL, 0);
+        const bool covered = n0 == TKF_WM || l0 == TKF_WM;
+#endif
+        if (r0 > 0 && d0 == 0u && covered && lane == TKF_NHL) BAD |= 1u;
         // (B) a white-space run that reaches the region end, goes on in the same document and started inside
         //     the commit range
         const uint32_t top = wv_readlane(SPR, 63);
-        if (r1 < n && (top & 0x8000u) && !starts_at_r1) {
+        if (r1 < n && (top & TKF_TOPBIT) && !starts_at_r1) {
             const uint32_t nz = ~cont & TKF_WM;
             const uint64_t NZ = wv_ballot(nz != 0u);
             int f = 0;
             if (NZ) {
                 const int tl = tk_msb64(NZ);
                 const uint32_t w = wv_readlane(nz, tl);
-                f = 16 * tl + (31 - __builtin_clz(w));
+                f = TKF_W * tl + (31 - __builtin_clz(w));
             }
             if (f < cb) {
                 const int at = f > ca ? f : ca;
-                if (lane == (at >> 4)) BAD |= 1u << (at & 15);
+                if (lane == (at >> TKF_LOGW)) BAD |= 1u << (at & (TKF_W - 1));
             }
         }
     }
 
     // ---- 5. enumerate the pieces: positions of the set bits of PS from the commit start on -------
-    const uint32_t PSown = PS & commit_mask;
-    const uint32_t PSlist = lane >= 2 ? PS : 0u;            // commit range and right halo (ends of the last pieces)
+    // One pass over all lanes when the pieces fit the LDS list (always with 16 bytes per lane; with 32 bytes per lane
+    // unless the region averages under two bytes per piece); otherwise two passes, lanes below 32 and lanes from 32 on.
+    uint32_t PSown = PS & commit_mask;
+    uint32_t PSlist = lane >= TKF_NHL ? PS : 0u;            // commit range and right halo (ends of the last pieces)
     uint32_t np_all, np_own, pfx_all, pfx_own;
     {
         // one scan for both counts (each < 2^16)
@@ -448,15 +499,79 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         pfx_all = pf & 0xFFFFu; pfx_own = pf >> 16;
         np_all = tot & 0xFFFFu; np_own = tot >> 16;
     }
+    const int npass = (TKF_W == 32 && np_all > TKF_MAXPIECES) ? 2 : 1;
+    const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
+    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
+    uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
+    uint32_t E = 0;                                         // slots beyond one per piece so far
+    uint32_t base_own = 0;                                  // pieces of the earlier pass
+    uint32_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;
+    uint32_t lane_lo = TKF_NHL, lane_hi = 64;               // lanes of the pass
+    // slot of every document that starts inside the lanes of the pass (and, with want_flags, the hand-back flags)
+    auto doc_outputs = [&](bool want_flags, bool anybad) {
+        // documents that touch the commit range: fd - 1 (the one that contains the region start) onwards
+        const uint64_t dfirst = fd > 0 ? fd - 1 : 0;
+        for (uint64_t base = dfirst;; base += 64) {
+            const uint64_t d = base + (uint64_t)lane;
+            int64_t s = INT64_MAX, e = INT64_MAX;
+            if (d < a.n_docs) {
+                s = (int64_t)a.doc_offs[d];
+                e = (int64_t)a.doc_offs[d + 1];
+            }
+            const bool in = s < c1;
+            if (in && s >= c0) {
+                // id slots of this chunk before the document's first byte (a document start is a piece start)
+                const uint32_t p = (uint32_t)(s - r0);
+                const uint32_t pl = p >> TKF_LOGW;
+                if (npass == 1 || (pl >= lane_lo && pl < lane_hi)) {
+                    const uint32_t pi = lds[TKF_L_PFX + pl] + (uint32_t)__builtin_popcount(lds[TKF_L_PS + pl] & ((1u << (p & (TKF_W - 1))) - 1u));
+                    a.lstart[d] = pi < np_own ? list[pi] : base_own + np_own + E;
+                }
+            }
+            if (want_flags && anybad && in && e > c0) {
+                // any bad position inside [s, e) clipped to the region?
+                const int64_t lo = s > r0 ? s - r0 : 0, hi = e < r1 ? e - r0 : TKF_REGION;
+                if (hi > lo) {
+                    const uint32_t pl = (uint32_t)lo, ph = (uint32_t)hi;
+                    const uint32_t cl = lds[TKF_L_BPFX + (pl >> TKF_LOGW)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (pl >> TKF_LOGW)] & ((1u << (pl & (TKF_W - 1))) - 1u));
+                    uint32_t ch;
+                    if (ph >= TKF_REGION) ch = lds[TKF_L_BPFX + 63] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + 63]);
+                    else ch = lds[TKF_L_BPFX + (ph >> TKF_LOGW)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (ph >> TKF_LOGW)] & ((1u << (ph & (TKF_W - 1))) - 1u));
+                    if (ch > cl) a.flags[d] = 1u;
+                }
+            }
+            if (wv_ballot(in) != ~0ull) break;
+        }
+    };
+  for (int pass = 0; pass < npass; ++pass) {
+    uint32_t sentinel = TKF_REGION;                         // end of the pass's last piece: the region end ...
+    if (npass == 2) {
+        lane_lo = pass ? 32 : TKF_NHL;
+        lane_hi = pass ? 64 : 32;
+        const bool mine = (uint32_t)lane >= lane_lo && (uint32_t)lane < lane_hi;
+        PSlist = mine ? PS : 0u;
+        PSown = PSlist & commit_mask;
+        uint32_t tot;
+        const uint32_t pf = tkf_scan_excl((uint32_t)__builtin_popcount(PSlist) | ((uint32_t)__builtin_popcount(PSown) << 16), lane, &tot);
+        pfx_all = pf & 0xFFFFu; pfx_own = pf >> 16;
+        np_all = tot & 0xFFFFu; np_own = tot >> 16;
+        if (pass == 0) {                                    // ... or the first piece start of the second pass
+            const uint64_t Bm = wv_ballot(lane >= 32 && PS != 0u);
+            if (Bm) {
+                const int fl = (int)__builtin_ctzll(Bm);
+                sentinel = (uint32_t)TKF_W * (uint32_t)fl + (uint32_t)__builtin_ctz(wv_readlane(PS, fl));
+            }
+        }
+    }
     {
         uint32_t w = PSlist, idx = pfx_all;
         while (wv_ballot(w != 0u)) {
             if (w) {
-                list[idx++] = (uint16_t)(16 * lane + __builtin_ctz(w));
+                list[idx++] = (uint16_t)(TKF_W * lane + __builtin_ctz(w));
                 w &= w - 1u;
             }
         }
-        if (lane == 0) list[np_all] = TKF_REGION;           // sentinel: the region end
+        if (lane == 0) list[np_all] = (uint16_t)sentinel;
     }
     lds[TKF_L_PS + lane] = PSown;
     lds[TKF_L_PFX + lane] = pfx_own;
@@ -465,18 +580,13 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // ---- 6. whole-piece lookup, one lane per piece; ids stored at once ---------------------------------
     // A piece that misses the vocabulary reserves `len` id slots (it cannot produce more ids than bytes) and is
     // queued for tk_merge_wave; the slots it does not fill stay TKF_HOLE and are squeezed out by the assembly.
-    const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
-    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
-    uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
-    uint32_t E = 0;                                         // slots beyond one per piece so far
-    uint32_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;
     const uint32_t nbatch = (np_own + 63u) / 64u;
     for (uint32_t j = 0; j < nbatch; ++j) {
         // Straight-line for the common case (a piece of up to 16 bytes): every lane fetches bytes and hashes -- a lane
         // without a piece takes position 0, length 1 -- and only the table loads are predicated.
         const uint32_t idx = j * 64u + (uint32_t)lane;
         const bool act = idx < np_own;
-        const uint32_t p0 = list[idx], p1 = list[idx + 1];  // (idx + 1 <= 960: inside the list words, whatever they hold)
+        const uint32_t p0 = list[idx < np_all ? idx : np_all], p1 = list[idx < np_all ? idx + 1 : np_all];   // (never past the sentinel)
         const uint32_t pos = act ? p0 : 0u;
         const uint32_t len = act ? p1 - p0 : 1u;
         // the piece's first 16 bytes from the LDS copy of the region (five aligned dwords, funnel-shifted), zeroed past the
@@ -519,11 +629,11 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 }
                 r = tk_probe_long(t, h1, h2, len, rbytes + pos);
             }
-            if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> 4), 1u << (pos & 15));
+            if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
         }
         // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
         const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
-        uint32_t slot = idx + E;
+        uint32_t slot = base_own + idx + E;
         if (wv_ballot(miss)) {
             // A miss reserves `len` id slots (it cannot produce more ids than bytes): one per piece + (len - 1) more for
             // every miss before it.  The misses are queued in the chunk's own region (no global atomics), records in
@@ -538,7 +648,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
             if (miss) {
                 const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
-                mq[qb + before] = pos | (len << 10) | (slot << 17);   // pos < 1024, len <= 64, slot < 992
+                mq[qb + before] = TKF_REC(pos, len, slot);
             }
             nm0 += ctot & 0xFFu;
             nm1 += (ctot >> 8) & 0xFFu;
@@ -551,8 +661,15 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             if (!miss && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
         }
     }
+    if (pass + 1 < npass) {
+        wv_lds_sync();                                      // the slots written by the last batch
+        doc_outputs(false, false);                          // the slots of this pass's documents, while its list is there
+        base_own += np_own;
+        wv_lds_sync();                                      // the list is rebuilt by the next pass
+    }
+  }
     if (lane == 0) {
-        a.kcount[c] = np_own + E;
+        a.kcount[c] = base_own + np_own + E;
         a.miss_count[c] = nm0;                       // class-major: class k of chunk c at [k * n_chunks + c]
         a.miss_count[a.n_chunks + c] = nm1;
         a.miss_count[2 * a.n_chunks + c] = nm2;
@@ -569,38 +686,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         lds[TKF_L_BPFX + lane] = bp;
     }
     wv_lds_sync();
-    {
-        // documents that touch the commit range: fd - 1 (the one that contains the region start) onwards
-        const uint64_t dfirst = fd > 0 ? fd - 1 : 0;
-        for (uint64_t base = dfirst;; base += 64) {
-            const uint64_t d = base + (uint64_t)lane;
-            int64_t s = INT64_MAX, e = INT64_MAX;
-            if (d < a.n_docs) {
-                s = (int64_t)a.doc_offs[d];
-                e = (int64_t)a.doc_offs[d + 1];
-            }
-            const bool in = s < c1;
-            if (in && s >= c0) {
-                // id slots of this chunk before the document's first byte (a document start is a piece start)
-                const uint32_t p = (uint32_t)(s - r0);
-                const uint32_t pi = lds[TKF_L_PFX + (p >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_PS + (p >> 4)] & ((1u << (p & 15)) - 1u));
-                a.lstart[d] = pi < np_own ? list[pi] : np_own + E;
-            }
-            if (anybad && in && e > c0) {
-                // any bad position inside [s, e) clipped to the region?
-                const int64_t lo = s > r0 ? s - r0 : 0, hi = e < r1 ? e - r0 : TKF_REGION;
-                if (hi > lo) {
-                    const uint32_t pl = (uint32_t)lo, ph = (uint32_t)hi;
-                    const uint32_t cl = lds[TKF_L_BPFX + (pl >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (pl >> 4)] & ((1u << (pl & 15)) - 1u));
-                    uint32_t ch;
-                    if (ph >= TKF_REGION) ch = lds[TKF_L_BPFX + 63] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + 63]);
-                    else ch = lds[TKF_L_BPFX + (ph >> 4)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (ph >> 4)] & ((1u << (ph & 15)) - 1u));
-                    if (ch > cl) a.flags[d] = 1u;
-                }
-            }
-            if (wv_ballot(in) != ~0ull) break;
-        }
-    }
+    doc_outputs(true, anybad);
     wv_lds_sync();  // the next chunk reuses the LDS slice
 }
 
@@ -764,7 +850,7 @@ TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* 
 template <bool WIDE>
 TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane) {
     const TkTablesView& t = a.t;
-    const uint32_t pos = rec & 1023u, len = (rec >> 10) & 127u, slot = rec >> 17;
+    const uint32_t pos = TKF_REC_POS(rec), len = TKF_REC_LEN(rec), slot = TKF_REC_SLOT(rec);
     const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
     uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
     uint32_t holes = 0;

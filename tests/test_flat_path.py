@@ -197,3 +197,16 @@ def test_emu_flat_region_geometry(small_vocab):
     assert 0 < len(flagged) < len(docs)
     # total length a multiple of the commit size, documents ending exactly on chunk / region boundaries
     _emu_check(small_vocab, [b"ab " * 309 + b"c", b"d" * 32, b"e f" * 298 + b"gh", b"", b"i" * 928, b"j k " * 232], True, True)
+
+
+def test_emu_flat_dense_pieces(test_vocab):
+    """Regions with more pieces than the LDS list of the 32-bytes-per-lane kernel holds (an average of under two bytes
+    per piece over 2 KB): the pieces are enumerated in two passes; document starts, misses and long runs on both sides."""
+    rng = random.Random(77)
+    docs = [(b"1,2,3,4,5,6,7,8,9,0;" * 300), b"a b c d e f g h i j " * 250, b"!a!b!c" * 700,
+            b"".join(bytes([rng.choice(b"0123456789,.;:-+ ")]) for _ in range(9000)),
+            b"x" * 40 + b"1,2," * 600 + b" zzzzzz " + b"3;4;" * 500]
+    docs += [b"7," * rng.randint(1, 40) for _ in range(300)]          # many short documents inside dense regions
+    docs += [(b"q" * 70 + b",1" * 900)]                                 # a piece over 64 bytes inside a dense region
+    flagged = _emu_check(test_vocab, docs)
+    assert len(flagged) <= 2

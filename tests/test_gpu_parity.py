@@ -375,3 +375,19 @@ def test_key_hash_fallback_kernel(tk, test_vocab):
         + helpers.random_unicode_docs(100)
     assert e.encode_docs(docs, True, True) == [orc.encode(d, True, True) for d in docs]
     e.close()
+
+
+def test_dense_piece_regions(tk, eng_small, test_vocab):
+    """Regions with more pieces than the LDS piece list holds (under two bytes per piece over 2 KB) take two enumeration
+    passes; nothing is handed back because of it."""
+    import random
+    rng = random.Random(77)
+    docs = [(b"1,2,3,4,5,6,7,8,9,0;" * 300), b"a b c d e f g h i j " * 250, b"!a!b!c" * 700,
+            b"".join(bytes([rng.choice(b"0123456789,.;:-+ ")]) for _ in range(9000)),
+            b"x" * 40 + b"1,2," * 600 + b" zzzzzz " + b"3;4;" * 500]
+    docs += [b"7," * rng.randint(1, 40) for _ in range(2000)]
+    docs += [(b"q" * 70 + b",1" * 900)]
+    orc = helpers.oracle_for(test_vocab)
+    data, offs = tk.pack_docs(docs)
+    check_batch(eng_small, orc, data, offs)
+    assert eng_small.last_stats()["handed_back"] <= 2

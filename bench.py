@@ -10,7 +10,7 @@ batch of synthetic documents already resident in HBM:
   N > 1 : configs[3] shape = 1 M x 512-byte documents PER GPU (weak scaling: 8 M over 8 GPUs),
           contiguous shards, plus the single RCCL gather of the id buffers to rank 0 inside the step.
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (tk_flat_kernel: split + lookup + merge, one wave per 1024-byte region)
+  roofline     -- the dominant kernel (tk_flat_kernel: split + lookup + merge, one wave per 2048-byte region)
                   against the HBM roofline:
                   algorithmic bytes (N_in + 8(D+1) + 4 T_out + 8(D+1)) per launch divided by
                   its mean duration measured live with HIP events on the launch stream

@@ -299,7 +299,7 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
     return TK_OK;
 }
 
-// The flat pipeline (tk_flat.hip): one wave per 1024-byte region of the packed stream, documents the
+// The flat pipeline (tk_flat.hip): one wave per 2048-byte region of the packed stream, documents the
 // fast path cannot take (non-ASCII, very long runs / pieces) redone by the per-document kernels.
 static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                              int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {

@@ -1,7 +1,7 @@
 // tk_flat.hip -- gfx950 kernels of the flat (chunk-per-wave) tokenization path, see tk_flat_impl.h.
 //
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
-//   tk_flat_kernel            split + lookup + merge of one 1024-byte region per wave, ids chunk-dense
+//   tk_flat_kernel            split + lookup of one region (64 x TKF_W bytes) per wave, ids chunk-dense
 //   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
 //   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32-wide register arrays / one lane per byte)
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel

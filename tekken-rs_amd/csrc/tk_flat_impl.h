@@ -3,9 +3,9 @@
 // Same computation as tk_encode_impl.h (CoreBPE::encode behind reference src/tekkenizer.rs:384-386, pattern
 // literal :123) but laid out for the machine instead of for the document:
 //
-//   * the packed text of ALL documents is cut into regions of 1024 bytes; a wave owns one region at a
-//     time, lane l owns bytes [16 l, 16 l + 16) and holds every class / rule mask as 16 bits of a VGPR
-//     ("lane layout": one VALU instruction = one mask operation over 1024 bytes; shifts borrow from
+//   * the packed text of ALL documents is cut into regions of 64 x TKF_W bytes (TKF_W = 32: 2048); a wave owns one
+//     region at a time, lane l owns bytes [W l, W l + W) and holds every class / rule mask as W bits of a VGPR
+//     ("lane layout": one VALU instruction = one mask operation over the whole region; shifts borrow from
 //     the neighbour lane with DPP, ripple carries cross lanes through a 64-bit carry look-ahead);
 //   * document boundaries are a mask (DS): look-behind shifts are cut at a document start, look-ahead
 //     shifts at a document end, runs are broken there -- documents never cost a branch;
@@ -20,7 +20,7 @@
 //     cut the stream into documents and squeeze the holes out.
 //
 // Regions overlap: 32 bytes of left halo (look-behind context), 64 of right halo (look-ahead, piece
-// ends), 928 committed.  ASCII is classified from the bit planes alone; a region with multi-byte code
+// ends), the rest committed (1952 bytes of 2048).  ASCII is classified from the bit planes alone; a region with multi-byte code
 // points additionally looks the class of every lead byte up in the trie (the char-level rules use the
 // char-start mask).  A document with a digit / CR-LF run that covers the whole left halo, a white-space
 // run that reaches the end of the region or a piece of more than 64 bytes is flagged and redone by the
@@ -73,7 +73,7 @@
 
 
 // ------------------------------------------------------------------------------------------
-// lane-layout mask primitives (16 bits per lane, bit i of lane l = region byte 16 l + i)
+// lane-layout mask primitives (TKF_W bits per lane, bit i of lane l = region byte W l + i)
 // ------------------------------------------------------------------------------------------
 // (own word above / below the neighbour's in one register, then ONE bit-field extract: 3 VALU per shift, and the
 // combined word is shared by shifts of the same mask)
@@ -103,7 +103,7 @@ TK_DEV uint32_t tkf_shr_any(uint32_t x, int k, int lane) {
 }
 TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
 
-// a + b over the whole 1024-bit region: per-lane add, then a 64-bit carry look-ahead over the lane carries
+// a + b over the whole region (64 x W bits): per-lane add, then a 64-bit carry look-ahead over the lane carries
 // (G = lanes that generate a carry, P = lanes that would pass one on) hands every lane its carry-in
 TK_DEV uint32_t tkf_add(uint32_t a, uint32_t b) {
     const uint32_t t = a + b;
@@ -131,7 +131,7 @@ TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
 }
 
 // ------------------------------------------------------------------------------------------
-// SWAR classification of 16 ASCII bytes per lane -> 16-bit masks
+// bit-plane classification of the lane's TKF_W bytes -> W-bit masks
 // ------------------------------------------------------------------------------------------
 struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
@@ -153,7 +153,7 @@ TK_DEV void tkf_transpose8(uint32_t& lo, uint32_t& hi) {
     hi ^= t >> 4;
 }
 
-// 16 bytes per lane -> the 8 bit planes (already in lane layout: bit i of plane b = bit b of byte i) -> the class
+// the lane's bytes -> the 8 bit planes (already in lane layout: bit i of plane b = bit b of byte i) -> the class
 // masks as boolean functions of the planes.  ASCII classes of the pattern of src/tekkenizer.rs:123: L = [A-Za-z],
 // N = [0-9], S = \s (9..13, 0x20); bytes >= 0x80 only set HI.
 TK_DEV TkfClass tkf_classify(const uint32_t* x) {
@@ -349,7 +349,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     }
     TkfClass m = tkf_classify(x);
     if (tkf_any(m.HI)) {
-        // multi-byte code points: every lane walks the lead bytes among its 16 bytes, decodes the code point, looks its
+        // multi-byte code points: every lane walks the lead bytes among its own bytes, decodes the code point, looks its
         // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
         uint32_t* cl = lds + TKF_L_CL;
         cl[lane] = 0u; cl[64 + lane] = 0u; cl[128 + lane] = 0u;

@@ -24,7 +24,7 @@ hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, 
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s);
 
-// ---- flat path (tk_flat.hip, tk_flat_impl.h): one wave per 1024-byte region of the packed stream ----
+// ---- flat path (tk_flat.hip, tk_flat_impl.h): one wave per 2048-byte region of the packed stream ----
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
                                    uint32_t* flags, uint32_t* holes, uint32_t* counters16, hipStream_t s);
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);

@@ -1,4 +1,4 @@
-"""The FLAT path (tekken-rs_amd/csrc/tk_flat_impl.h: one wave per 1024-byte region of the packed stream, masks
+"""The FLAT path (tekken-rs_amd/csrc/tk_flat_impl.h: one wave per 2048-byte region of the packed stream, masks
 in lane layout, document boundaries as a mask) on the CPU:
   * tools/flat_split_model.py -- the rules as mask algebra on Python ints -- against the oracle split;
   * the device source on the wave emulator (tests/emu) against the oracle, id for id, including the
@@ -49,7 +49,7 @@ def test_model_random_and_runs():
     for _ in range(120):
         docs = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, rng.choice([3, 40, 300])))).encode()
                 for _ in range(rng.randint(1, 40))]
-        _model_check(docs, region=rng.choice([256, 1024]))
+        _model_check(docs, region=rng.choice([256, 1024, 2048]))
     alpha2 = list("a1 \n!'s")
     for _ in range(120):
         docs = ["".join(rng.choice(alpha2) * rng.choice([1, 1, 1, 2, 5, 40, 100]) for _ in range(rng.randint(0, 30))).encode()
@@ -134,7 +134,7 @@ def test_model_utf8():
     for _ in range(150):
         docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 7, 20]) for _ in range(rng.randint(0, 25))).encode()
                 for _ in range(rng.randint(1, 12))]
-        _model_check(docs, region=rng.choice([256, 1024]))
+        _model_check(docs, region=rng.choice([256, 1024, 2048]))
 
 
 def test_emu_flat_utf8(test_vocab):
@@ -181,8 +181,8 @@ def test_key_hash_fallback_mode(test_vocab):
 
 
 def _boundary_docs(pads, lens):
-    """runs of every class placed so that they start / end around the region geometry (32-byte left halo, 928 committed,
-    64-byte right halo, 64-byte piece limit)"""
+    """runs of every class placed so that they start / end around the region geometry (32-byte left halo, 928 or 1952
+    bytes committed -- 16 or 32 bytes per lane --, 64-byte right halo, 64-byte piece limit)"""
     docs = []
     for pad in pads:
         for ch in ("1", "\n", " ", "a", "!", "中", "１"):
@@ -192,11 +192,13 @@ def _boundary_docs(pads, lens):
 
 
 def test_emu_flat_region_geometry(small_vocab):
-    docs = _boundary_docs((864, 896, 927, 928, 960), (31, 32, 33, 64, 65))
-    flagged = _emu_check(small_vocab, docs, False, False, check_split=True)
-    assert 0 < len(flagged) < len(docs)
+    for pads in ((864, 896, 927, 928, 960), (1888, 1920, 1951, 1952, 1984)):
+        docs = _boundary_docs(pads, (31, 32, 33, 64, 65))
+        flagged = _emu_check(small_vocab, docs, False, False, check_split=True)
+        assert 0 < len(flagged) < len(docs)
     # total length a multiple of the commit size, documents ending exactly on chunk / region boundaries
     _emu_check(small_vocab, [b"ab " * 309 + b"c", b"d" * 32, b"e f" * 298 + b"gh", b"", b"i" * 928, b"j k " * 232], True, True)
+    _emu_check(small_vocab, [b"ab " * 650 + b"cd", b"d" * 32, b"e f" * 639 + b"ghi", b"", b"i" * 1952, b"j k " * 488], True, True)
 
 
 def test_emu_flat_dense_pieces(test_vocab):

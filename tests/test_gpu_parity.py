@@ -152,7 +152,7 @@ def test_flat_path_stress(eng_small, test_vocab):
              for _ in range(1500)]
     docs += helpers.random_unicode_docs(1500, seed=12, max_len=300)
     # runs of every class that start / end around the region geometry (halos, commit size, piece limit), every phase
-    for pad in list(range(860, 1000, 3)):
+    for pad in list(range(860, 1000, 3)) + list(range(1880, 2030, 5)):
         for ch in ("1", "\n", " ", "a", "!", "\u4e2d", "\uff11"):
             for rl in (31, 32, 33, 63, 64, 65):
                 docs.append(("x y " * (pad // 4) + "q" * (pad % 4) + ch * rl + " z").encode())

@@ -18,6 +18,7 @@ One JSON line is printed by rank 0 (contract in the task statement) with two ext
                   here) timed single-thread on this box's host cores on the same documents
 """
 import argparse
+import collections
 import importlib
 import json
 import os
@@ -45,6 +46,9 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--gather", choices=["overlap", "sync"], default="overlap",
+                    help="N > 1: gather of batch k beside the kernels of batch k + 1 (default) or inside the step, blocking")
+    ap.add_argument("--wire", type=int, choices=[18, 32], default=18, help="N > 1: bits per id on the wire")
     ap.add_argument("--host-steps", type=int, default=3, help="host-to-host leg (row f-4): timed passes, 0 = skip")
     ap.add_argument("--decode-steps", type=int, default=5, help="extra leg: GPU batch decode of the produced ids (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -61,7 +65,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("TK_BENCH_FORCE_DIST") == "1"   # (the override: the N > 1 code path on one GPU)
     if args.gpus != world and distributed:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and not distributed:
@@ -70,6 +74,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -95,6 +100,19 @@ def main():
     pipe_ms = []
     n_ids_local = 0
     gathered = None
+    # N > 1: the link into rank 0 bounds the job.  The ids travel in the 18-bit wire format when the
+    # vocabulary allows it, and the gather of batch k runs beside the kernels of batch k + 1 (at most two in flight);
+    # every gather is complete before the clock stops.
+    codec = None
+    if distributed and xdev == "cuda" and args.wire == 18 and tokz.vocab_size() <= (1 << 18):
+        codec = par.Ids18Codec(tk, eng)
+    overlap = distributed and args.gather == "overlap"
+    pending = collections.deque()
+
+    def drain(keep):
+        nonlocal gathered
+        while len(pending) > keep:
+            gathered = pending.popleft().result()
 
     def step():
         nonlocal n_ids_local, gathered
@@ -106,11 +124,18 @@ def main():
         if distributed:
             ids = torch.as_tensor(v_ids, device="cuda")
             oo = torch.as_tensor(v_oo, device="cuda")
-            gathered = par.gather_ids(ids.to(xdev), (oo[1:] - oo[:-1]).to(xdev), dst=0)
+            cnt = oo[1:] - oo[:-1]
+            if overlap:
+                # (a private copy: the context's output buffer belongs to the next call)
+                pending.append(par.gather_ids(ids.clone().to(xdev), cnt.to(xdev), dst=0, codec=codec, wait=False))
+                drain(1)
+            else:
+                gathered = par.gather_ids(ids.to(xdev), cnt.to(xdev), dst=0, codec=codec)
         return v_ids, v_oo
 
     for _ in range(args.warmup):
         step()
+    drain(0)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -119,6 +144,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         v_ids, v_oo = step()
+    drain(0)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -158,7 +184,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d x %d-byte %s docs per GPU (%s)" % (
                 n_docs, args.doc_len, {"ascii": "ASCII (G-ascii)", "mixed": "mixed UTF-8 (G-mixed)", "zipf": "Zipf-length"}[args.kind],
-                "BASELINE configs[1]" if not distributed else "BASELINE configs[3] shape, RCCL gather to rank 0 in the step"),
+                "BASELINE configs[1]" if not distributed else "BASELINE configs[3] shape, RCCL gather to rank 0 in the step (%s, %d-bit ids on the wire)" % (args.gather, 18 if codec else 32)),
                 "docs_total": n_docs * world, "input_bytes_total": total_bytes, "ids_total": total_ids,
                 "vocab": vocab_kind, "add_bos": True, "add_eos": True, "sharding": "contiguous whole documents per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

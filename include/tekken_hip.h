@@ -133,6 +133,16 @@ int tk_decode_batch_device(tk_ctx* ctx, const void* d_ids, const void* d_id_offs
                            int policy, void* hip_stream, void** d_bytes, void** d_out_offsets, uint64_t* n_bytes,
                            uint64_t* bad_doc);
 
+/* 18-bit wire format of token ids for the multi-GPU gather (no reference equivalent: the reference is one process on a
+ * CPU; BASELINE north_star asks for "a single RCCL gather of token-id buffers over xGMI").  The link into the
+ * gathering GPU bounds the job, and an id below 2^18 -- every Tekken vocabulary -- travels as 2.25 bytes instead of 4.
+ * All pointers are device memory of the context's device; the work is enqueued on hip_stream and NOT waited for
+ * (tk_pack_ids18_device returns after the stream has drained only because it has to report an id >= 2^18 as
+ * TK_ERR_INVALID_ARG).  tk_ids18_bytes(n) = size of the packed form of n ids. */
+uint64_t tk_ids18_bytes(uint64_t n_ids);
+int tk_pack_ids18_device(tk_ctx* ctx, const void* d_ids, uint64_t n_ids, void* d_packed, void* hip_stream);
+int tk_unpack_ids18_device(tk_ctx* ctx, const void* d_packed, uint64_t n_ids, void* d_ids, void* hip_stream);
+
 /* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
 int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);

@@ -113,6 +113,12 @@ def lib():
     L.tk_encode_batch_pipelined.restype = ctypes.c_int
     L.tk_encode_batch_pipelined.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, u32p,
                                             ctypes.c_uint64, u64p, u64p]
+    L.tk_ids18_bytes.restype = ctypes.c_uint64
+    L.tk_ids18_bytes.argtypes = [ctypes.c_uint64]
+    L.tk_pack_ids18_device.restype = ctypes.c_int
+    L.tk_pack_ids18_device.argtypes = [vp, vp, ctypes.c_uint64, vp, vp]
+    L.tk_unpack_ids18_device.restype = ctypes.c_int
+    L.tk_unpack_ids18_device.argtypes = [vp, vp, ctypes.c_uint64, vp, vp]
     L.tk_ctx_set_special_tokens.restype = ctypes.c_int
     L.tk_ctx_set_special_tokens.argtypes = [vp, u8p, u32p, ctypes.c_uint32]
     L.tk_decode_batch.restype = ctypes.c_int
@@ -291,6 +297,18 @@ class Engine:
         p_ids, p_oo, n = self.encode_batch_device(d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos, add_eos, stream)
         return DeviceView(p_ids, n, "<i4"), DeviceView(p_oo, n_docs + 1, "<i8")
 
+    def pack_ids18_device(self, d_ids_ptr, n_ids, d_packed_ptr, stream=0):
+        """ids (uint32, device) -> 18-bit wire format (ids18_bytes(n_ids) bytes, device); raises if an id needs more bits."""
+        rc = lib().tk_pack_ids18_device(self._h, ctypes.c_void_p(d_ids_ptr), n_ids, ctypes.c_void_p(d_packed_ptr), ctypes.c_void_p(stream))
+        if rc != TK_OK:
+            raise self._err(rc)
+
+    def unpack_ids18_device(self, d_packed_ptr, n_ids, d_ids_ptr, stream=0):
+        """18-bit wire format -> ids (uint32, device); enqueued on `stream`, not waited for."""
+        rc = lib().tk_unpack_ids18_device(self._h, ctypes.c_void_p(d_packed_ptr), n_ids, ctypes.c_void_p(d_ids_ptr), ctypes.c_void_p(stream))
+        if rc != TK_OK:
+            raise self._err(rc)
+
     def set_special_tokens(self, strings):
         """Special-token strings by position (needed by decode with SpecialTokenPolicy.Keep)."""
         raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in strings]
@@ -377,6 +395,10 @@ class _Pinned:
             lib().tk_host_free(ctypes.c_void_p(self.ptr))
         except Exception:
             pass
+
+
+def ids18_bytes(n_ids):
+    return int(lib().tk_ids18_bytes(int(n_ids)))
 
 
 def host_empty(n, dtype):

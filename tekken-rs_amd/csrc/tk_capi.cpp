@@ -650,6 +650,35 @@ extern "C" int tk_encode_batch_pipelined(tk_ctx* c, const uint8_t* bytes, const 
     return TK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// 18-bit wire format of ids (multi-GPU gather)
+// ------------------------------------------------------------------------------------------
+extern "C" uint64_t tk_ids18_bytes(uint64_t n_ids) { return ((2 * n_ids + 3) & ~3ull) + 4 * ((n_ids + 15) / 16); }
+
+extern "C" int tk_pack_ids18_device(tk_ctx* c, const void* d_ids, uint64_t n_ids, void* d_packed, void* hip_stream) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if ((!d_ids || !d_packed) && n_ids) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    TK_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    uint32_t* d_bad = (uint32_t*)c->counters.p + 8;
+    TK_HIP(c, hipMemsetAsync(d_bad, 0, 4, s));
+    TK_HIP(c, tk_launch_pack18((const uint32_t*)d_ids, n_ids, d_packed, d_bad, s));
+    TK_HIP(c, hipMemcpyAsync(c->h_pin + 8, d_bad, 4, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    if (c->h_pin[8]) { c->err = "an id does not fit 18 bits"; return TK_ERR_INVALID_ARG; }
+    return TK_OK;
+}
+
+extern "C" int tk_unpack_ids18_device(tk_ctx* c, const void* d_packed, uint64_t n_ids, void* d_ids, void* hip_stream) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if ((!d_ids || !d_packed) && n_ids) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    TK_HIP(c, hipSetDevice(c->device));
+    TK_HIP(c, tk_launch_unpack18(d_packed, n_ids, (uint32_t*)d_ids, (hipStream_t)hip_stream));
+    return TK_OK;
+}
+
 extern "C" void tk_free_result(tk_result* r) {
     if (!r) return;
     if (r->ids) (void)hipHostFree(r->ids);

@@ -252,3 +252,80 @@ hipError_t tk_launch_wave_selftest(uint32_t* d_fail, hipStream_t s) {
     hipLaunchKernelGGL(tk_wave_selftest_kernel, dim3(1), dim3(64), 0, s, d_fail);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// 18-bit wire format of token ids for the multi-GPU gather: the xGMI link into rank 0 is what
+// bounds N > 1, and an id of a Tekken vocabulary (< 2^18) travels as 2.25 bytes instead of 4:
+//   [ n x u16 low halves | padded to 4 bytes | ceil(n / 16) x u32, two high bits of 16 ids each ]
+// One thread per 16 ids (64 contiguous bytes in, 32 + 4 out); an id >= 2^18 raises *d_bad.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_pack18_kernel(const uint32_t* __restrict__ ids, uint64_t n, uint16_t* __restrict__ lows,
+                                                        uint32_t* __restrict__ highs, uint32_t* __restrict__ d_bad) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, i0 = g * 16;
+    if (i0 >= n) return;
+    uint32_t v[16];
+    if (i0 + 16 <= n) {
+        const uint4* src = reinterpret_cast<const uint4*>(ids + i0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = i0 + q < n ? ids[i0 + q] : 0u;
+    }
+    uint32_t hi = 0, over = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { hi |= ((v[q] >> 16) & 3u) << (2 * q); over |= v[q] >> 18; }
+    if (over) atomicOr(d_bad, 1u);
+    highs[g] = hi;
+    if (i0 + 16 <= n) {
+        uint4* dst = reinterpret_cast<uint4*>(lows + i0);   // i0 is a multiple of 16: 32-byte aligned
+        uint4 a, b;
+        a.x = (v[0] & 0xFFFFu) | (v[1] << 16); a.y = (v[2] & 0xFFFFu) | (v[3] << 16); a.z = (v[4] & 0xFFFFu) | (v[5] << 16); a.w = (v[6] & 0xFFFFu) | (v[7] << 16);
+        b.x = (v[8] & 0xFFFFu) | (v[9] << 16); b.y = (v[10] & 0xFFFFu) | (v[11] << 16); b.z = (v[12] & 0xFFFFu) | (v[13] << 16); b.w = (v[14] & 0xFFFFu) | (v[15] << 16);
+        dst[0] = a; dst[1] = b;
+    } else {
+        for (int q = 0; q < 16 && i0 + q < n; ++q) lows[i0 + q] = (uint16_t)v[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void tk_unpack18_kernel(const uint16_t* __restrict__ lows, const uint32_t* __restrict__ highs, uint64_t n,
+                                                          uint32_t* __restrict__ ids) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, i0 = g * 16;
+    if (i0 >= n) return;
+    const uint32_t hi = highs[g];
+    if (i0 + 16 <= n) {
+        const uint4* src = reinterpret_cast<const uint4*>(lows + i0);
+        const uint4 a = src[0], b = src[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4* dst = reinterpret_cast<uint4*>(ids + i0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 o;
+            o.x = (w[2 * q] & 0xFFFFu) | (((hi >> (8 * q)) & 3u) << 16);
+            o.y = (w[2 * q] >> 16) | (((hi >> (8 * q + 2)) & 3u) << 16);
+            o.z = (w[2 * q + 1] & 0xFFFFu) | (((hi >> (8 * q + 4)) & 3u) << 16);
+            o.w = (w[2 * q + 1] >> 16) | (((hi >> (8 * q + 6)) & 3u) << 16);
+            dst[q] = o;
+        }
+    } else {
+        for (int q = 0; q < 16 && i0 + q < n; ++q) ids[i0 + q] = (uint32_t)lows[i0 + q] | (((hi >> (2 * q)) & 3u) << 16);
+    }
+}
+
+hipError_t tk_launch_pack18(const uint32_t* ids, uint64_t n, void* packed, uint32_t* d_bad, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint16_t* lows = reinterpret_cast<uint16_t*>(packed);
+    uint32_t* highs = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(packed) + ((2 * n + 3) & ~3ull));
+    const uint64_t groups = (n + 15) / 16;
+    hipLaunchKernelGGL(tk_pack18_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, ids, n, lows, highs, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t tk_launch_unpack18(const void* packed, uint64_t n, uint32_t* ids, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint16_t* lows = reinterpret_cast<const uint16_t*>(packed);
+    const uint32_t* highs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(packed) + ((2 * n + 3) & ~3ull));
+    const uint64_t groups = (n + 15) / 16;
+    hipLaunchKernelGGL(tk_unpack18_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, lows, highs, n, ids);
+    return hipGetLastError();
+}

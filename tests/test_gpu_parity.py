@@ -391,3 +391,51 @@ def test_dense_piece_regions(tk, eng_small, test_vocab):
     data, offs = tk.pack_docs(docs)
     check_batch(eng_small, orc, data, offs)
     assert eng_small.last_stats()["handed_back"] <= 2
+
+
+def test_ids18_wire_format(tk, eng_small):
+    """The 18-bit wire format of the multi-GPU gather (tk_pack_ids18_device / tk_unpack_ids18_device): byte for byte the
+    layout the header describes (checked against the numpy restatement the gloo tests use), exact round trip for every
+    tail length, an id of 2^18 refused."""
+    import torch
+    from test_parallel_gloo import NumpyIds18Codec
+    ref = NumpyIds18Codec()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 15, 16, 17, 31, 33, 1000, 65537, 1 << 20):
+        ids = rng.integers(0, 1 << 18, n, dtype=np.int64).astype(np.uint32)
+        if n > 3:
+            ids[:3] = [0, (1 << 18) - 1, 1 << 16]
+        d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+        nb = tk.ids18_bytes(n)
+        assert nb == ref.nbytes(n)
+        d_packed = torch.zeros((nb + 3) // 4 + 1, dtype=torch.int32, device="cuda")
+        eng_small.pack_ids18_device(d_ids.data_ptr(), n, d_packed.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        exp = ref.pack(torch.from_numpy(ids.view(np.int32)))
+        assert np.array_equal(d_packed.cpu().numpy()[:exp.numel()], exp.numpy())
+        d_out = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        eng_small.unpack_ids18_device(d_packed.data_ptr(), n, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        assert np.array_equal(out[:n].view(np.uint32), ids) and out[n] == -1
+    bad = torch.tensor([5, 1 << 18, 7], dtype=torch.int32, device="cuda")
+    buf = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(tk.TokenizerError):
+        eng_small.pack_ids18_device(bad.data_ptr(), 3, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+
+def test_bench_distributed_path_single_rank():
+    """bench.py's N > 1 code path (RCCL process group, size exchange, side-stream gather, deferred results) with a
+    world of one rank: everything but the peer-to-peer transfers themselves."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TK_BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29577")
+    for gather in ("overlap", "sync"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--docs", "20000", "--steps", "3", "--warmup", "1",
+                            "--gather", gather], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["ids_total"] > 0

@@ -21,6 +21,40 @@ def _free_port():
     return p
 
 
+class NumpyIds18Codec:
+    """The 18-bit wire format of include/tekken_hip.h (tk_ids18_bytes) on CPU tensors -- TEST infrastructure for the
+    gather logic under gloo; the product codec is parallel.Ids18Codec (HIP kernels)."""
+
+    @staticmethod
+    def nbytes(n):
+        return ((2 * n + 3) & ~3) + 4 * ((n + 15) // 16)
+
+    def packed_numel(self, n):
+        return (self.nbytes(n) + 3) // 4
+
+    def pack(self, ids):
+        import torch
+        v = ids.numpy().view(np.uint32)
+        n = len(v)
+        assert n == 0 or int(v.max()) < (1 << 18)
+        out = np.zeros(self.packed_numel(n) * 4, np.uint8)
+        out[:2 * n] = (v & 0xFFFF).astype(np.uint16).view(np.uint8)
+        hi = np.zeros(((n + 15) // 16) * 16, np.uint32)
+        hi[:n] = (v >> 16) & 3
+        words = (hi.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+        h0 = (2 * n + 3) & ~3
+        out[h0:h0 + 4 * len(words)] = words.view(np.uint8)
+        return torch.from_numpy(out.view(np.int32).copy())
+
+    def unpack(self, packed, n, out):
+        raw = packed.numpy().view(np.uint8)
+        lows = raw[:2 * n].view(np.uint16).astype(np.uint32)
+        h0 = (2 * n + 3) & ~3
+        words = raw[h0:h0 + 4 * ((n + 15) // 16)].view(np.uint32)
+        hi = ((words[:, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(-1)[:n]
+        out.numpy().view(np.uint32)[:] = lows | (hi << 16)
+
+
 def _worker(rank, world, port, out_path):
     for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -46,6 +80,22 @@ def _worker(rank, world, port, out_path):
             # empty shard edge: more ranks than documents
             with open(out_path, "w") as f:
                 f.write("ok" if ok else "mismatch")
+        # the 18-bit wire format and the non-blocking form (two gathers in flight, results taken in order)
+        import torch
+        cuts = par.shard_by_bytes(offs, world)
+        d0, d1 = cuts[rank], cuts[rank + 1]
+        lids, loo = orc.encode_batch(data[int(offs[d0]):int(offs[d1])], (offs[d0:d1 + 1] - offs[d0]).astype(np.uint64), True, True)
+        t_ids = torch.from_numpy(np.ascontiguousarray(lids).view(np.int32))
+        t_cnt = torch.from_numpy(np.diff(loo.astype(np.int64)))
+        codec = NumpyIds18Codec()
+        p1 = par.gather_ids(t_ids, t_cnt, dst=0, codec=codec, wait=False)
+        p2 = par.gather_ids(t_ids.clone(), t_cnt.clone(), dst=0, codec=None, wait=False)
+        for pend in (p1, p2):
+            g_ids, g_offs = pend.result()
+            if rank == 0:
+                if not (np.array_equal(g_ids.numpy().view(np.uint32), eids) and np.array_equal(g_offs.numpy().astype(np.uint64), eoo)):
+                    with open(out_path, "w") as f:
+                        f.write("mismatch-codec")
         # a second round where one rank has nothing to send
         data2, offs2 = data[:int(offs[1])], offs[:2]
         ids2, oo2 = par.encode_sharded(enc, data2, offs2, False, False, dst=0)

@@ -213,7 +213,8 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
     TK_HIP(c, hipStreamSynchronize(s));
     const uint64_t maxlen = maxlen32;
     if (dbg) fprintf(stderr, "[tk] pass2: n_def=%u maxlen=%llu\n", n_def, (unsigned long long)maxlen);
-    const uint64_t words = ((4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;  // 16-byte aligned slices
+    // nodes (4 words per byte) | block minima | successor tokens (1 word per byte); 16-byte aligned slices
+    const uint64_t words = ((5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;
     // the grid is launched in blocks of 4 waves and EVERY launched wave owns a scratch slice
     uint64_t waves2 = n_def < 1024 ? n_def : 1024;
     const uint64_t budget_words = (8ull << 30) / 4;

@@ -194,6 +194,14 @@ TK_DEV uint64_t tk_wave_min64(uint64_t v, int lane) {
     return v;
 }
 
+// minimum of (rank << 32 | pos) over the wave with the DPP reduction (two 32-bit minima: the rank, then the position
+// among the lanes that hold it) -- about 150 clocks instead of the 1 500 of the bpermute butterfly on 64-bit values
+TK_DEV uint64_t tk_wave_min_key(uint32_t rank, uint32_t pos) {
+    const uint32_t r = wv_min_u32(rank);
+    const uint32_t p = wv_min_u32(rank == r ? pos : 0xFFFFFFFFu);
+    return r == TK_RANK_MAX ? ~0ull : (((uint64_t)r << 32) | (uint64_t)p);
+}
+
 TK_DEV TkPolyPow tk_poly_pow(const TkTablesView& t, int lane) {
     TkPolyPow p;
     p.pw1 = 1u; p.ipw1 = 1u; p.pw2 = 1u; p.ipw2 = 1u;
@@ -365,61 +373,136 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         node[i] = v;
     }
     wv_sync();
-    for (uint32_t blk = 0; blk < nb; ++blk) {
-        const uint32_t x = blk * 64u + (uint32_t)lane;
-        const uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
-        const uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
-        const uint64_t m = tk_wave_min64(key, lane);
-        if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
-    }
-    wv_sync();
-    for (uint32_t merges = 0; merges < nn; ++merges) {  // at most nn - 1 merges can happen
-        if (a.dbg_mark && lane == 0) a.dbg_mark[2] = merges;
-        uint64_t best = ~0ull;
-        for (uint32_t bq = (uint32_t)lane; bq < nb; bq += 64u) {
-            const uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
-            best = v < best ? v : best;
-        }
-        best = tk_wave_min64(best, lane);
-        if (wv_ballot(best != ~0ull) == 0) break;  // decided on a ballot => a scalar branch
-        const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
-        const tk_u32x4 Ni = node[i];
-        const uint32_t j = Ni.z, p = Ni.w;
-        const tk_u32x4 Nj = node[j];
-        const tk_u32x4 Np = node[p != TK_NONE ? p : i];
-        const uint32_t k = Nj.z;
-        const uint32_t tok_k = node[k < nn ? k : i].x;
-        uint32_t new_i, new_p;
-        tk_probe_pair_x2(t, rr, tok_k, Np.x, rr, new_i, new_p);
-        if (k >= nn) new_i = TK_RANK_MAX;
-        if (p == TK_NONE) new_p = TK_RANK_MAX;
-        wv_sync();  // every lane has read the nodes before lane 0 rewrites them
-        if (lane == 0) {
-            tk_u32x4 v;
-            v.x = rr; v.y = new_i; v.z = k; v.w = p;
-            node[i] = v;
-            v.x = TK_DEAD; v.y = TK_RANK_MAX; v.z = Nj.z; v.w = Nj.w;
-            node[j] = v;
-            if (k < nn) node[k].w = i;
-            if (p != TK_NONE) node[p].y = new_p;
-        }
-        // refresh the block minima of i, j and p; the three just-written ranks are patched in registers
-        const uint32_t bi = i / 64u, bj = j / 64u, bp = (p != TK_NONE) ? p / 64u : bi;
-        const bool skip1 = wv_ballot(bj != bi) == 0;
-        const bool skip2 = wv_ballot(bp != bi && bp != bj) == 0;
-        for (int q = 0; q < 3; ++q) {
-            if ((q == 1 && skip1) || (q == 2 && skip2)) continue;
-            const uint32_t blk = q == 0 ? bi : q == 1 ? bj : bp;
+    if (nb <= 512u) {
+        // ---- up to 32 KiB: the block minima live in REGISTERS (lane l holds blocks l, l + 64, ...: 8 slots), every node
+        // carries the token of its successor (tokn), and the rows of the (at most three) blocks whose minimum changes are
+        // requested together with nodes j and p.  Dependent round trips per merge: node i | nodes j, p, tokn[j], rows |
+        // the two re-probes | the stores' acknowledgement -- four instead of seven.
+        uint32_t* tokn = bmin + 2u * nb;
+        for (uint32_t i = (uint32_t)lane; i < nn; i += 64u) tokn[i] = (i + 1u < nn) ? (uint32_t)a.bytes[w0 + i + 1u] : 0u;
+        uint64_t bm[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bm[q] = ~0ull;
+        for (uint32_t blk = 0; blk < nb; ++blk) {
             const uint32_t x = blk * 64u + (uint32_t)lane;
-            uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
-            if (x == i) rk = new_i;
-            if (x == j) rk = TK_RANK_MAX;
-            if (p != TK_NONE && x == p) rk = new_p;
+            const uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
+            const uint64_t m = tk_wave_min_key(rk, x);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if ((uint32_t)q == (blk >> 6) && (uint32_t)lane == (blk & 63u)) bm[q] = m;
+        }
+        wv_sync();
+        for (uint32_t merges = 0; merges < nn; ++merges) {  // at most nn - 1 merges can happen
+            uint64_t best = bm[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) best = bm[q] < best ? bm[q] : best;
+            best = tk_wave_min_key((uint32_t)(best >> 32), (uint32_t)best);   // (~0: rank MAX)
+            if (best == ~0ull) break;                        // wave-uniform
+            const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
+            const tk_u32x4 Ni = node[i];
+            const uint32_t j = Ni.z, p = Ni.w;
+            const uint32_t bi = i / 64u, bj = j / 64u, bp = (p != TK_NONE) ? p / 64u : bi;
+            // one round trip: the two neighbours, the token behind j, the rank rows of the blocks to refresh
+            const tk_u32x4 Nj = node[j];
+            const tk_u32x4 Np = node[p != TK_NONE ? p : i];
+            const uint32_t tok_k = tokn[j];
+            uint32_t row[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const uint32_t blk = q == 0 ? bi : q == 1 ? bj : bp;
+                const uint32_t x = blk * 64u + (uint32_t)lane;
+                row[q] = x < nn ? node[x].y : TK_RANK_MAX;
+            }
+            const uint32_t k = Nj.z;
+            uint32_t new_i, new_p;
+            tk_probe_pair_x2(t, rr, tok_k, Np.x, rr, new_i, new_p);
+            if (k >= nn) new_i = TK_RANK_MAX;
+            if (p == TK_NONE) new_p = TK_RANK_MAX;
+            wv_sync();  // every lane has read the nodes before lane 0 rewrites them
+            if (lane == 0) {
+                tk_u32x4 v;
+                v.x = rr; v.y = new_i; v.z = k; v.w = p;
+                node[i] = v;
+                tokn[i] = tok_k;                             // i's successor is now k
+                v.x = TK_DEAD; v.y = TK_RANK_MAX; v.z = Nj.z; v.w = Nj.w;
+                node[j] = v;
+                if (k < nn) node[k].w = i;
+                if (p != TK_NONE) { node[p].y = new_p; tokn[p] = rr; }
+            }
+            // refresh the block minima of i, j and p from the rows, with the three just-written ranks patched in
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const uint32_t blk = q == 0 ? bi : q == 1 ? bj : bp;
+                if ((q == 1 && bj == bi) || (q == 2 && (bp == bi || bp == bj))) continue;   // (wave-uniform)
+                const uint32_t x = blk * 64u + (uint32_t)lane;
+                uint32_t rk = row[q];
+                if (x == i) rk = new_i;
+                if (x == j) rk = TK_RANK_MAX;
+                if (p != TK_NONE && x == p) rk = new_p;
+                const uint64_t m = tk_wave_min_key(rk, x);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if ((uint32_t)u == (blk >> 6) && (uint32_t)lane == (blk & 63u)) bm[u] = m;
+            }
+            wv_sync();  // this merge's stores are visible before the next merge's loads
+        }
+    } else {
+        for (uint32_t blk = 0; blk < nb; ++blk) {
+            const uint32_t x = blk * 64u + (uint32_t)lane;
+            const uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
             const uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
             const uint64_t m = tk_wave_min64(key, lane);
             if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
         }
-        wv_sync();  // this merge's stores are visible before the next merge's loads
+        wv_sync();
+        for (uint32_t merges = 0; merges < nn; ++merges) {  // at most nn - 1 merges can happen
+            if (a.dbg_mark && lane == 0) a.dbg_mark[2] = merges;
+            uint64_t best = ~0ull;
+            for (uint32_t bq = (uint32_t)lane; bq < nb; bq += 64u) {
+                const uint64_t v = ((uint64_t)bmin[2 * bq + 1] << 32) | bmin[2 * bq];
+                best = v < best ? v : best;
+            }
+            best = tk_wave_min64(best, lane);
+            if (wv_ballot(best != ~0ull) == 0) break;  // decided on a ballot => a scalar branch
+            const uint32_t i = (uint32_t)best, rr = (uint32_t)(best >> 32);
+            const tk_u32x4 Ni = node[i];
+            const uint32_t j = Ni.z, p = Ni.w;
+            const tk_u32x4 Nj = node[j];
+            const tk_u32x4 Np = node[p != TK_NONE ? p : i];
+            const uint32_t k = Nj.z;
+            const uint32_t tok_k = node[k < nn ? k : i].x;
+            uint32_t new_i, new_p;
+            tk_probe_pair_x2(t, rr, tok_k, Np.x, rr, new_i, new_p);
+            if (k >= nn) new_i = TK_RANK_MAX;
+            if (p == TK_NONE) new_p = TK_RANK_MAX;
+            wv_sync();  // every lane has read the nodes before lane 0 rewrites them
+            if (lane == 0) {
+                tk_u32x4 v;
+                v.x = rr; v.y = new_i; v.z = k; v.w = p;
+                node[i] = v;
+                v.x = TK_DEAD; v.y = TK_RANK_MAX; v.z = Nj.z; v.w = Nj.w;
+                node[j] = v;
+                if (k < nn) node[k].w = i;
+                if (p != TK_NONE) node[p].y = new_p;
+            }
+            // refresh the block minima of i, j and p; the three just-written ranks are patched in registers
+            const uint32_t bi = i / 64u, bj = j / 64u, bp = (p != TK_NONE) ? p / 64u : bi;
+            const bool skip1 = wv_ballot(bj != bi) == 0;
+            const bool skip2 = wv_ballot(bp != bi && bp != bj) == 0;
+            for (int q = 0; q < 3; ++q) {
+                if ((q == 1 && skip1) || (q == 2 && skip2)) continue;
+                const uint32_t blk = q == 0 ? bi : q == 1 ? bj : bp;
+                const uint32_t x = blk * 64u + (uint32_t)lane;
+                uint32_t rk = x < nn ? node[x].y : TK_RANK_MAX;
+                if (x == i) rk = new_i;
+                if (x == j) rk = TK_RANK_MAX;
+                if (p != TK_NONE && x == p) rk = new_p;
+                const uint64_t key = rk == TK_RANK_MAX ? ~0ull : (((uint64_t)rk << 32) | x);
+                const uint64_t m = tk_wave_min64(key, lane);
+                if (lane == 0) { bmin[2 * blk] = (uint32_t)m; bmin[2 * blk + 1] = (uint32_t)(m >> 32); }
+            }
+            wv_sync();  // this merge's stores are visible before the next merge's loads
+        }
     }
     if (a.dbg_mark && lane == 0) a.dbg_mark[0] = 5u;
     for (uint32_t blk = 0; blk < nb; ++blk) {

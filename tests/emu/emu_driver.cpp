@@ -59,7 +59,7 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
     ops += tkemu::g_wave->n_ops;
     if (n_deferred) *n_deferred = defer_count;
     if (defer_count) {
-        std::vector<uint32_t> scratch_raw(4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
+        std::vector<uint32_t> scratch_raw(5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
         uint32_t* scratch_al = scratch_raw.data();
         while (reinterpret_cast<uintptr_t>(scratch_al) % 16) ++scratch_al;
         a.todo_list = defer_list.data();
@@ -182,7 +182,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             uint64_t maxlen = 0;
             for (uint32_t i = 0; i < defer_count; ++i)
                 maxlen = std::max<uint64_t>(maxlen, doc_offs[defer_list[i] + 1] - doc_offs[defer_list[i]]);
-            std::vector<uint32_t> scratch_raw(4 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
+            std::vector<uint32_t> scratch_raw(5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);
             uint32_t* scratch_al = scratch_raw.data();
             while (reinterpret_cast<uintptr_t>(scratch_al) % 16) ++scratch_al;
             std::vector<uint32_t> todo2(defer_list.begin(), defer_list.begin() + defer_count);

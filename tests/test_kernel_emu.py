@@ -69,3 +69,16 @@ def test_emu_split_long_ascii_windows(small_vocab):
     _, starts, _ = emu.encode_batch(small_vocab["tokens"], 10, 1, 2, docs, split_only=True)
     for d, s in zip(docs, starts):
         assert s == tk_oracle.split(d), d
+
+
+def test_emu_long_single_piece(test_vocab):
+    """One piece of several thousand bytes (pass 2, the cooperative merge with its block minima in registers: more than
+    64 blocks, so more than one register slot per lane), random and periodic content."""
+    import random
+    rng = random.Random(9)
+    o = helpers.oracle_for(test_vocab)
+    docs = ["".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(4500)).encode(), b"ab" * 2300, b"x" * 4200 + b"yz"]
+    got, _, n_def = emu.encode_batch(test_vocab["tokens"], test_vocab["num_special"], 1, 2, docs, True, True)
+    assert n_def == len(docs)
+    for doc, g in zip(docs, got):
+        assert g == o.encode(doc, True, True)

@@ -114,6 +114,27 @@ def main():
         while len(pending) > keep:
             gathered = pending.popleft().result()
 
+    if distributed and (overlap or codec is not None):
+        # a small rehearsal of the packed / overlapped gather; if it raises on ANY rank, every rank falls back to the
+        # plain form (32-bit ids, blocking) -- the ranks agree through an all_reduce so that nobody is left waiting
+        ok = 1
+        try:
+            t_ids = (torch.arange(1000, dtype=torch.int32, device="cuda") * 131 % 200000).to(xdev)
+            t_cnt = torch.full((10,), 100, dtype=torch.int64, device=xdev)
+            res = par.gather_ids(t_ids, t_cnt, dst=0, codec=codec, wait=not overlap)
+            res = res.result() if overlap else res
+            if rank == 0:
+                exp = torch.cat([t_ids] * world)
+                if not (res[0].numel() == exp.numel() and bool(torch.equal(res[0], exp))):
+                    ok = 0
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("[bench] packed / overlapped gather failed in the rehearsal (%r): falling back\n" % (e,))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            codec, overlap = None, False
+
     def step():
         nonlocal n_ids_local, gathered
         v_ids, v_oo = eng.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, True, True, stream)
@@ -184,7 +205,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d x %d-byte %s docs per GPU (%s)" % (
                 n_docs, args.doc_len, {"ascii": "ASCII (G-ascii)", "mixed": "mixed UTF-8 (G-mixed)", "zipf": "Zipf-length"}[args.kind],
-                "BASELINE configs[1]" if not distributed else "BASELINE configs[3] shape, RCCL gather to rank 0 in the step (%s, %d-bit ids on the wire)" % (args.gather, 18 if codec else 32)),
+                "BASELINE configs[1]" if not distributed else "BASELINE configs[3] shape, RCCL gather to rank 0 in the step (%s, %d-bit ids on the wire)" % ("overlap" if overlap else "sync", 18 if codec else 32)),
                 "docs_total": n_docs * world, "input_bytes_total": total_bytes, "ids_total": total_ids,
                 "vocab": vocab_kind, "add_bos": True, "add_eos": True, "sharding": "contiguous whole documents per GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

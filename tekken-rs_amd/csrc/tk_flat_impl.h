@@ -634,26 +634,41 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
         const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
         uint32_t slot = base_own + idx + E;
-        if (wv_ballot(miss)) {
+        const uint64_t MB = wv_ballot(miss);
+        if (MB) {
             // A miss reserves `len` id slots (it cannot produce more ids than bytes): one per piece + (len - 1) more for
             // every miss before it.  The misses are queued in the chunk's own region (no global atomics), records in
             // piece order, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one
-            // class per wave.  Rank inside the class: ONE scan over four packed 8-bit counters (<= 64 misses per batch).
-            uint32_t tot;
-            slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
-            E += tot;
-            const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
-            const uint32_t sh = cls * 8u;
-            uint32_t ctot;
-            const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
-            if (miss) {
-                const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
-                mq[qb + before] = TKF_REC(pos, len, slot);
+            // class per wave.  The two common cases are cheap: ONE miss in the batch (its extra slots shift the lanes
+            // behind it: one readlane) and misses of the first class only (rank inside the class = misses before the
+            // lane: mbcnt); otherwise a DPP scan of the extra slots and ONE scan over four packed 8-bit counters.
+            if ((MB & (MB - 1ull)) == 0ull) {
+                const int src = tk_ctz64(MB);
+                const uint32_t extra = wv_readlane(len, src) - 1u;
+                if (lane > src) slot += extra;
+                E += extra;
+            } else {
+                uint32_t tot;
+                slot += tkf_scan_excl(miss ? len - 1u : 0u, lane, &tot);
+                E += tot;
             }
-            nm0 += ctot & 0xFFu;
-            nm1 += (ctot >> 8) & 0xFFu;
-            nm2 += (ctot >> 16) & 0xFFu;
-            nm3 += ctot >> 24;
+            if (wv_ballot(miss && len > 8u) == 0ull) {
+                if (miss) mq[TKF_MISSOFF0 + nm0 + (uint32_t)tk_popc64(MB & tk_lowmask(lane))] = TKF_REC(pos, len, slot);
+                nm0 += (uint32_t)tk_popc64(MB);
+            } else {
+                const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
+                const uint32_t sh = cls * 8u;
+                uint32_t ctot;
+                const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
+                if (miss) {
+                    const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
+                    mq[qb + before] = TKF_REC(pos, len, slot);
+                }
+                nm0 += ctot & 0xFFu;
+                nm1 += (ctot >> 8) & 0xFFu;
+                nm2 += (ctot >> 16) & 0xFFu;
+                nm3 += ctot >> 24;
+            }
         }
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {

@@ -18,10 +18,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--vocab", choices=["small", "bench"], default="small")
     a = ap.parse_args()
     import helpers
     tk = importlib.import_module("tekken-rs_amd")
-    v = helpers.small_trained_vocab()
+    if a.vocab == "bench":
+        import synth_vocab as sv
+        toks, ns, bos, eos = sv.load_tokens(sv.ensure_default())
+        v = {"tokens": toks, "num_special": ns, "bos": bos, "eos": eos}
+    else:
+        v = helpers.small_trained_vocab()
     orc = helpers.oracle_for(v)
     eng = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
     rng = random.Random(a.seed)

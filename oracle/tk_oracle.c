@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "tk_unicode_tables2.h"
+
 #define CLS_O 0
 #define CLS_L 1
 #define CLS_N 2
@@ -167,6 +169,145 @@ static size_t match_at(const uint8_t* t, size_t n, size_t pos) {
     }
 }
 
+/* ---------------------------------------------------------------------------------------
+ * SURVEY section 8 row f-3 (groundwork, NOT on the device yet): the `pattern` that Mistral's tekken.json carries and the
+ * reference ignores (src/tekkenizer.rs:74; literal in tests/test_small_vocab.rs:62):
+ *   [^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+
+ *  |[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*
+ *  |\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+
+ * Classes (tk_unicode_tables2.h): U = Lu|Lt, W = Ll, X = Lm|Lo, M = marks, N, S, O.  A = U|X|M, B = W|X|M.
+ * Leftmost-first alternation, greedy quantifiers with backtracking -- pinned against Python `regex`
+ * (tests/golden/split_vectors_tekken.json).
+ * ------------------------------------------------------------------------------------- */
+#define C2_O 0
+#define C2_U 1
+#define C2_W 2
+#define C2_X 3
+#define C2_M 4
+#define C2_N 5
+#define C2_S 6
+
+int tk_oracle_class2(uint32_t cp) {
+    if (cp >= 0x110000u) return C2_O;
+    uint32_t blk = TK_UC2_STAGE1[cp >> 7];
+    uint32_t w = TK_UC2_STAGE2[blk * 16 + ((cp & 127) >> 3)];
+    return (int)((w >> (4 * (cp & 7))) & 15u);
+}
+static int cls2_at(const uint8_t* t, size_t n, size_t p, size_t* len, uint32_t* cp) {
+    uint32_t c = decode(t, n, p, len);
+    *cp = c;
+    return tk_oracle_class2(c);
+}
+static int in_A(int k) { return k == C2_U || k == C2_X || k == C2_M; }
+static int in_B(int k) { return k == C2_W || k == C2_X || k == C2_M; }
+static int is_letter2(int k) { return k == C2_U || k == C2_W || k == C2_X; }
+
+/* [A]*[B]+ at p with backtracking: returns the end of the match, or p if it fails */
+static size_t word1_at(const uint8_t* t, size_t n, size_t p) {
+    /* the maximal run of A from p, remembering the last position inside it whose char is also in B (X or M) */
+    size_t q = p, last_b = (size_t)-1;
+    while (q < n) {
+        size_t l; uint32_t c;
+        int k = cls2_at(t, n, q, &l, &c);
+        if (!in_A(k)) break;
+        if (in_B(k)) last_b = q;
+        q += l;
+    }
+    size_t k0 = (size_t)-1;
+    if (q < n) {                       /* greedy A* took everything: does B+ start right behind it? */
+        size_t l; uint32_t c;
+        if (in_B(cls2_at(t, n, q, &l, &c))) k0 = q;
+    }
+    if (k0 == (size_t)-1) k0 = last_b; /* give A chars back until one of them can open B+ */
+    if (k0 == (size_t)-1) return p;
+    size_t e = k0;
+    while (e < n) {
+        size_t l; uint32_t c;
+        if (!in_B(cls2_at(t, n, e, &l, &c))) break;
+        e += l;
+    }
+    return e;
+}
+/* [A]+[B]* at p: end of the match, or p if it fails */
+static size_t word2_at(const uint8_t* t, size_t n, size_t p) {
+    size_t q = p;
+    while (q < n) {
+        size_t l; uint32_t c;
+        if (!in_A(cls2_at(t, n, q, &l, &c))) break;
+        q += l;
+    }
+    if (q == p) return p;
+    while (q < n) {
+        size_t l; uint32_t c;
+        if (!in_B(cls2_at(t, n, q, &l, &c))) break;
+        q += l;
+    }
+    return q;
+}
+
+static size_t match2_at(const uint8_t* t, size_t n, size_t pos) {
+    size_t l0;
+    uint32_t c0;
+    const int k0 = cls2_at(t, n, pos, &l0, &c0);
+    const int prefix_ok = !(is_crlf(c0) || is_letter2(k0) || k0 == C2_N);
+    /* alt 1, alt 2: optional one-char prefix (greedy: with it first), then the word */
+    for (int alt = 1; alt <= 2; ++alt) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            size_t p;
+            if (attempt == 0) { if (!prefix_ok || pos + l0 >= n) continue; p = pos + l0; }
+            else p = pos;
+            const size_t e = alt == 1 ? word1_at(t, n, p) : word2_at(t, n, p);
+            if (e > p) return e;
+        }
+    }
+    /* alt 3: \p{N} */
+    if (k0 == C2_N) return pos + l0;
+    /* alt 4:  ?[^\s\p{L}\p{N}]+[\r\n/]*   (the class is O or M) */
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        size_t p;
+        if (attempt == 0) { if (c0 != ' ') continue; p = pos + 1; }
+        else p = pos;
+        size_t q = p;
+        while (q < n) {
+            size_t l; uint32_t c;
+            int k = cls2_at(t, n, q, &l, &c);
+            if (!(k == C2_O || k == C2_M)) break;
+            q += l;
+        }
+        if (q > p) {
+            while (q < n && (t[q] == '\r' || t[q] == '\n' || t[q] == '/')) ++q;
+            return q;
+        }
+    }
+    /* white space: the same three alternatives as the hard-coded pattern */
+    {
+        size_t e = pos, after_last_nl = 0, last_char = pos;
+        int has_nl = 0;
+        while (e < n) {
+            size_t l; uint32_t c;
+            if (cls2_at(t, n, e, &l, &c) != C2_S) break;
+            last_char = e;
+            e += l;
+            if (is_crlf(c)) { has_nl = 1; after_last_nl = e; }
+        }
+        if (e == pos) return pos + l0;       /* (unreachable for valid UTF-8: every class is covered above) */
+        if (has_nl) return after_last_nl;
+        if (e == n) return e;
+        if (last_char > pos) return last_char;
+        return e;
+    }
+}
+
+size_t tk_oracle_split_tekken(const uint8_t* text, size_t n, uint32_t* starts, size_t cap) {
+    size_t pos = 0, k = 0;
+    while (pos < n) {
+        if (k < cap) starts[k] = (uint32_t)pos;
+        ++k;
+        pos = match2_at(text, n, pos);
+    }
+    return k;
+}
+
 size_t tk_oracle_split(const uint8_t* text, size_t n, uint32_t* starts, size_t cap) {
     size_t pos = 0, k = 0;
     while (pos < n) {
@@ -185,6 +326,7 @@ struct tk_oracle {
     uint32_t* offs;
     uint32_t n_ranks;
     uint32_t num_special, bos_id, eos_id;
+    int pattern;     /* 0 = the hard-coded pattern (reference behaviour), 1 = the JSON pattern of row f-3 */
     uint32_t* slots; /* rank+1, 0 = empty */
     uint32_t mask;
     uint32_t byte_rank[256];
@@ -245,6 +387,8 @@ tk_oracle* tk_oracle_new(const uint8_t* blob, const uint32_t* offs, uint32_t n_r
     }
     return o;
 }
+
+void tk_oracle_set_pattern(tk_oracle* o, int pattern) { if (o) o->pattern = pattern ? 1 : 0; }
 
 void tk_oracle_free(tk_oracle* o) {
     if (!o) return;
@@ -307,7 +451,7 @@ static size_t encode_doc(const tk_oracle* o, const uint8_t* text, size_t n, int 
     size_t first = k;
     size_t pos = 0;
     while (pos < n) {                                                 /* regex.find_iter(text) */
-        size_t end = match_at(text, n, pos);
+        size_t end = o->pattern ? match2_at(text, n, pos) : match_at(text, n, pos);
         uint32_t r = rank_of(o, text + pos, end - pos);               /* whole-piece shortcut */
         if (r != RANK_MAX) { if (k < cap) out[k] = r; ++k; }
         else k = bpe_piece(o, text + pos, end - pos, out, cap, k, scratch, scratch_cap);

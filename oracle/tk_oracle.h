@@ -37,6 +37,14 @@ void tk_oracle_free(tk_oracle* o);
  * number of pieces (which may exceed cap; only cap are written).  Vocab-free. */
 size_t tk_oracle_split(const uint8_t* text, size_t n, uint32_t* starts, size_t cap);
 
+/* SURVEY section 8 row f-3 (groundwork): the split under the `pattern` string of Mistral's tekken.json (literal in
+ * reference tests/test_small_vocab.rs:62), which the reference ignores (src/tekkenizer.rs:74).  Pinned against
+ * Python `regex` (tests/golden/split_vectors_tekken.json).  tk_oracle_set_pattern(o, 1) makes tk_oracle_encode* use
+ * it (0, the default, is the reference's behaviour).  4-bit class: 0=O 1=U(Lu|Lt) 2=W(Ll) 3=X(Lm|Lo) 4=M 5=N 6=S. */
+size_t tk_oracle_split_tekken(const uint8_t* text, size_t n, uint32_t* starts, size_t cap);
+void tk_oracle_set_pattern(tk_oracle* o, int pattern);
+int tk_oracle_class2(uint32_t cp);
+
 /* Tekkenizer::encode(text, add_bos, add_eos) (src/tekkenizer.rs:378-405) for ONE document.
  * Returns the number of ids (may exceed cap; only cap are written). */
 size_t tk_oracle_encode(const tk_oracle* o, const uint8_t* text, size_t n, int add_bos,

@@ -40,6 +40,11 @@ def lib():
         L.tk_oracle_encode_batch.restype = ctypes.c_uint64
         L.tk_oracle_encode_batch.argtypes = [ctypes.c_void_p, u8p, u64p, ctypes.c_uint64, ctypes.c_int,
                                              ctypes.c_int, u32p, u64p, ctypes.c_int]
+        L.tk_oracle_split_tekken.restype = ctypes.c_size_t
+        L.tk_oracle_split_tekken.argtypes = [u8p, ctypes.c_size_t, u32p, ctypes.c_size_t]
+        L.tk_oracle_set_pattern.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.tk_oracle_class2.restype = ctypes.c_int
+        L.tk_oracle_class2.argtypes = [ctypes.c_uint32]
         L.tk_oracle_class.restype = ctypes.c_int
         L.tk_oracle_class.argtypes = [ctypes.c_uint32]
         L.tk_oracle_fnv1a.restype = ctypes.c_uint64
@@ -58,6 +63,15 @@ def split(text: bytes):
     buf = np.frombuffer(text, dtype=np.uint8) if n else np.zeros(1, np.uint8)
     starts = np.zeros(max(n, 1), np.uint32)
     k = lib().tk_oracle_split(_p(buf, ctypes.c_uint8), n, _p(starts, ctypes.c_uint32), n)
+    return starts[:k].tolist()
+
+
+def split_tekken(text: bytes):
+    """Piece start offsets under the JSON pattern of Mistral's tekken.json (row f-3 groundwork)."""
+    n = len(text)
+    buf = np.frombuffer(text, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+    starts = np.zeros(max(n, 1), np.uint32)
+    k = lib().tk_oracle_split_tekken(_p(buf, ctypes.c_uint8), n, _p(starts, ctypes.c_uint32), n)
     return starts[:k].tolist()
 
 

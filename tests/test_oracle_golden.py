@@ -125,3 +125,32 @@ def test_batch_equals_single(test_vocab):
         ids, oo = o.encode_batch(data, offs, True, True, threads=threads)
         for d, doc in enumerate(docs):
             assert ids[int(oo[d]):int(oo[d + 1])].tolist() == o.encode(doc, True, True)
+
+
+def test_tekken_pattern_split_matches_independent_engine():
+    """SURVEY 8 row f-3, groundwork: the oracle's matcher for the `pattern` string of Mistral's tekken.json (the one the
+    reference ignores) against golden vectors from Python `regex` (tools/gen_golden_tekken.py) -- case-aware word
+    splitting (Lu / Lt / Ll / Lm / Lo / M classes), single digits, '/' absorbed after punctuation."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "split_vectors_tekken.json")) as f:
+        g = json.load(f)
+    assert "\\p{Lu}" in g["pattern"] and len(g["cases"]) > 900
+    for c in g["cases"]:
+        assert tk_oracle.split_tekken(c["text"].encode("utf-8")) == c["starts"], c["text"]
+    # the two patterns differ where they should
+    assert tk_oracle.split(b"HelloWorld 1234") == [0, 10, 11, 14] and tk_oracle.split_tekken(b"HelloWorld 1234") == [0, 5, 10, 11, 12, 13, 14]
+
+
+def test_tekken_pattern_live_against_python_regex():
+    import random
+    regex = pytest.importorskip("regex")
+    import synth_vocab as sv
+    R = regex.compile(sv.MISTRAL_PATTERN)
+    rng = random.Random(8)
+    alpha = list("aAbB zZ") + ["é", "É", "ǅ", "ʰ", "中", "ª", "́", "̈", "1", "٣", "²",
+                               " ", "\n", "\r", "\t", "!", "/", "-", "'", "_", " ", "　", "\U0001f642"]
+    for _ in range(20000):
+        s = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 16)))
+        exp = [len(s[:m.start()].encode()) for m in R.finditer(s)]
+        assert tk_oracle.split_tekken(s.encode()) == exp, repr(s)

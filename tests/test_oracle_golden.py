@@ -144,6 +144,7 @@ def test_tekken_pattern_split_matches_independent_engine():
 
 def test_tekken_pattern_live_against_python_regex():
     import random
+    import pytest
     regex = pytest.importorskip("regex")
     import synth_vocab as sv
     R = regex.compile(sv.MISTRAL_PATTERN)

@@ -80,6 +80,13 @@ int tk_encode_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offse
                     int add_bos, int add_eos, int validate_utf8, tk_result* out);
 void tk_free_result(tk_result* r);
 
+/* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
+ * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference
+ * tests/test_small_vocab.rs:62 -- instead of the pattern the reference hard-codes and always uses
+ * (src/tekkenizer.rs:74,123).  mode 0 (default) = the reference's behaviour, 1 = the JSON pattern.  First version:
+ * every document takes the sequential piece-by-piece path (exact, an order of magnitude slower than mode 0). */
+int tk_ctx_set_pattern(tk_ctx* ctx, int mode);
+
 /* Streaming / pipelined ingestion (same results as tk_encode_batch, which is what the reference's
  * `encode` returns per document).  The batch is cut into slices of whole documents (about slice_bytes of text each,
  * 0 = default 32 MiB) that go through a three-stage pipeline on three HIP streams: host->device copy of slice k+1, the
@@ -179,6 +186,10 @@ int tk_tokenizer_encode(tk_tokenizer* t, const char* text, size_t len, int add_b
 int tk_tokenizer_encode_batch(tk_tokenizer* t, const uint8_t* bytes, const uint64_t* doc_offsets,
                               uint64_t n_docs, int add_bos, int add_eos, tk_result* out);
 void tk_free_ids(uint32_t* ids);
+/* Opt-in (row f-3): honour the `pattern` of the loaded tekken.json instead of ignoring it like the reference does
+ * (src/tekkenizer.rs:74).  Only Mistral's pattern string is known; any other is refused with TK_ERR_INVALID_CONFIG.
+ * See tk_ctx_set_pattern. */
+int tk_tokenizer_set_honour_pattern(tk_tokenizer* t, int honour);
 
 /* Batch decode on the GPU (needs a device-backed tokenizer); see tk_decode_batch. */
 int tk_tokenizer_decode_batch(tk_tokenizer* t, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs,

@@ -92,6 +92,10 @@ class Oracle:
         self._h = lib().tk_oracle_new(_p(blob, ctypes.c_uint8), _p(offs, ctypes.c_uint32), len(self.tokens),
                                       num_special, bos_id, eos_id)
 
+    def set_pattern(self, mode):
+        """0 = the hard-coded pattern (reference behaviour), 1 = the JSON pattern of Mistral's tekken.json (row f-3)."""
+        lib().tk_oracle_set_pattern(self._h, int(mode))
+
     def __del__(self):
         try:
             if self._h:

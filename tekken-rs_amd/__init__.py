@@ -119,6 +119,10 @@ def lib():
     L.tk_pack_ids18_device.argtypes = [vp, vp, ctypes.c_uint64, vp, vp]
     L.tk_unpack_ids18_device.restype = ctypes.c_int
     L.tk_unpack_ids18_device.argtypes = [vp, vp, ctypes.c_uint64, vp, vp]
+    L.tk_ctx_set_pattern.restype = ctypes.c_int
+    L.tk_ctx_set_pattern.argtypes = [vp, ctypes.c_int]
+    L.tk_tokenizer_set_honour_pattern.restype = ctypes.c_int
+    L.tk_tokenizer_set_honour_pattern.argtypes = [vp, ctypes.c_int]
     L.tk_ctx_set_special_tokens.restype = ctypes.c_int
     L.tk_ctx_set_special_tokens.argtypes = [vp, u8p, u32p, ctypes.c_uint32]
     L.tk_decode_batch.restype = ctypes.c_int
@@ -309,6 +313,12 @@ class Engine:
         if rc != TK_OK:
             raise self._err(rc)
 
+    def set_pattern(self, mode):
+        """0 = the reference's hard-coded pattern (default), 1 = the JSON pattern of Mistral's tekken.json (opt-in, row f-3)."""
+        rc = lib().tk_ctx_set_pattern(self._h, int(mode))
+        if rc != TK_OK:
+            raise self._err(rc)
+
     def set_special_tokens(self, strings):
         """Special-token strings by position (needed by decode with SpecialTokenPolicy.Keep)."""
         raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in strings]
@@ -451,6 +461,12 @@ class Tekkenizer:
 
     def _err(self, rc):
         return TokenizerError(rc, lib().tk_tokenizer_last_error(self._h).decode())
+
+    def set_honour_pattern(self, honour=True):
+        """Opt-in (row f-3): use the `pattern` of the loaded tekken.json instead of ignoring it like the reference does."""
+        rc = lib().tk_tokenizer_set_honour_pattern(self._h, int(bool(honour)))
+        if rc != TK_OK:
+            raise self._err(rc)
 
     def encode(self, text, add_bos=False, add_eos=False):
         """Tekkenizer::encode (src/tekkenizer.rs:378-405)."""

@@ -566,8 +566,10 @@ Tekkenizer* Tekkenizer::from_json(const char* json, size_t len, int device_id, T
         return nullptr;
     }
     const std::vector<SpecialTokenInfo> sp = md.has_special_tokens ? md.special_tokens : deprecated_special_tokens();
-    return create(md.vocab, sp, md.config.pattern, md.config.default_vocab_size, md.config.default_num_special_tokens, v,
-                  md.has_audio, device_id, err);
+    Tekkenizer* t = create(md.vocab, sp, md.config.pattern, md.config.default_vocab_size, md.config.default_num_special_tokens, v,
+                           md.has_audio, device_id, err);
+    if (t) t->pattern_ = md.config.pattern;
+    return t;
 }
 
 // ---- model cache ----
@@ -712,6 +714,21 @@ Tekkenizer* Tekkenizer::from_file(const std::string& path, int device_id, Tokeni
     Tekkenizer* t = from_json(content.data(), content.size(), device_id, err);
     if (t && !side.empty()) (void)t->save_model_cache(side, key);   // best effort
     return t;
+}
+
+// the `pattern` of Mistral's tekken.json (literal in reference tests/test_small_vocab.rs:62)
+static const char* kTekkenJsonPattern =
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+|"
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|"
+    "\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
+TokenizerError Tekkenizer::set_honour_pattern(bool honour) {
+    if (!ctx_) return mk(TK_ERR_NO_DEVICE, "no device context");
+    if (honour && pattern_ != kTekkenJsonPattern)
+        return mk(TK_ERR_INVALID_CONFIG, "unsupported pattern: only the pattern of Mistral's tekken.json can be honoured");
+    const int rc = tk_ctx_set_pattern(ctx_, honour ? 1 : 0);
+    if (rc != TK_OK) return mk(rc, tk_last_error(ctx_));
+    return TokenizerError();
 }
 
 TokenizerError Tekkenizer::get_control_token(const std::string& name, uint32_t& id) const {  // :331-341
@@ -890,6 +907,11 @@ extern "C" int tk_tokenizer_encode_batch(tk_tokenizer* h, const uint8_t* bytes, 
                                          uint64_t n_docs, int add_bos, int add_eos, tk_result* out) {
     if (!h || !doc_offsets || !out) return TK_ERR_INVALID_ARG;
     return finish(h, h->t->encode_batch(bytes, doc_offsets, n_docs, add_bos != 0, add_eos != 0, out));
+}
+
+extern "C" int tk_tokenizer_set_honour_pattern(tk_tokenizer* h, int honour) {
+    if (!h) return TK_ERR_INVALID_ARG;
+    return finish(h, h->t->set_honour_pattern(honour != 0));
 }
 
 extern "C" void tk_free_ids(uint32_t* ids) { free(ids); }

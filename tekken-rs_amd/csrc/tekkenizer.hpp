@@ -95,6 +95,10 @@ public:
     const std::vector<std::string>& vocab() const { return vocab_; }
 
     tk_ctx* ctx() { return ctx_; }
+    // row f-3 (opt-in): honour the JSON `pattern` the file carried.  Only the pattern of Mistral's tekken.json is known
+    // to the matcher; any other string is refused.  honour = false restores the reference's behaviour (pattern ignored).
+    TokenizerError set_honour_pattern(bool honour);
+    const std::string& json_pattern() const { return pattern_; }
     const std::vector<uint8_t>& rank_blob() const { return blob_; }
     const std::vector<uint32_t>& rank_offsets() const { return offs_; }
     std::string last_error;
@@ -120,6 +124,7 @@ private:
     std::vector<uint8_t> blob_;                                  // rank table: bytes of rank i
     std::vector<uint32_t> offs_;
     bool has_audio_ = false;
+    std::string pattern_;                                        // config.pattern as loaded (ignored unless opted in)
 };
 
 // helpers exposed for tests

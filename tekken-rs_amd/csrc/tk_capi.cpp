@@ -53,7 +53,8 @@ struct tk_ctx {
     std::string err;
     TkHostTables host;
     TkTablesView dview;
-    DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs;
+    DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs, t_uc2a, t_uc2b;
+    int pattern = 0;               // tk_ctx_set_pattern: 0 the reference's hard-coded pattern, 1 the JSON pattern (row f-3)
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
@@ -134,6 +135,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
                 (unsigned long long)h.n_key_spill_slots, h.pair_mask + 1, (unsigned long long)h.n_pairs);
     if ((rc = upload(c, c->t_uc1, h.uc_stage1.data(), h.uc_stage1.size() * 2)) ||
         (rc = upload(c, c->t_uc2, h.uc_stage2.data(), h.uc_stage2.size() * 4)) ||
+        (rc = upload(c, c->t_uc2a, h.uc2_stage1.data(), h.uc2_stage1.size() * 2)) ||
+        (rc = upload(c, c->t_uc2b, h.uc2_stage2.data(), h.uc2_stage2.size() * 4)) ||
         (rc = upload(c, c->t_key8, h.key8_tab.data(), h.key8_tab.size() * sizeof(tk_key8_entry))) ||
         (rc = upload(c, c->t_key, h.key_tab.data(), h.key_tab.size() * sizeof(tk_key_entry))) ||
         (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
@@ -145,6 +148,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview = h.host_view();
     c->dview.uc_stage1 = (const uint16_t*)c->t_uc1.p;
     c->dview.uc_stage2 = (const uint32_t*)c->t_uc2.p;
+    c->dview.uc2_stage1 = (const uint16_t*)c->t_uc2a.p;
+    c->dview.uc2_stage2 = (const uint32_t*)c->t_uc2b.p;
     c->dview.key8_tab = (const tk_key8_entry*)c->t_key8.p;
     c->dview.key_tab = (const tk_key_entry*)c->t_key.p;
     c->dview.long_tab = (const tk_long_entry*)c->t_long.p;
@@ -175,7 +180,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
+    DevBuf* bufs[] = {&c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
@@ -198,13 +203,21 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     delete c;
 }
 
+extern "C" int tk_ctx_set_pattern(tk_ctx* c, int mode) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (mode != 0 && mode != 1) { c->err = "pattern mode must be 0 (hard-coded pattern) or 1 (tekken.json pattern)"; return TK_ERR_INVALID_ARG; }
+    c->pattern = mode;
+    return TK_OK;
+}
+
 extern "C" const char* tk_last_error(const tk_ctx* c) { return c ? c->err.c_str() : g_tls_err.c_str(); }
 
 const TkHostTables* tk_ctx_host_tables(const tk_ctx* c) { return c ? &c->host : nullptr; }
 
 // Pass 2 over the n_def documents of c->defer_list: documents with a long piece that missed the vocabulary need the
 // scratch-backed cooperative merge.  The scratch is sized from the longest deferred document.
-static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_t n_def, hipStream_t s) {
+static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_t n_def, hipStream_t s, uint64_t max_waves = 1024) {
     const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
     uint32_t maxlen32 = 0;
     TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 3, 0, 4, s));
@@ -216,7 +229,7 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
     // nodes (4 words per byte) | block minima | successor tokens (1 word per byte); 16-byte aligned slices
     const uint64_t words = ((5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;
     // the grid is launched in blocks of 4 waves and EVERY launched wave owns a scratch slice
-    uint64_t waves2 = n_def < 1024 ? n_def : 1024;
+    uint64_t waves2 = n_def < max_waves ? n_def : max_waves;
     const uint64_t budget_words = (8ull << 30) / 4;
     if (waves2 * words > budget_words) waves2 = budget_words / words;
     waves2 = ((waves2 + 3) / 4) * 4;
@@ -430,9 +443,58 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     return TK_OK;
 }
 
+// Row f-3, opt-in (tk_ctx_set_pattern(ctx, 1)): the JSON pattern of tekken.json.  First version: EVERY document takes the
+// piece-by-piece path of pass 2 with the sequential matcher tk_match_end2 (one wave per document); the flat kernel's
+// mask rules for this pattern are the next step.
+static int run_pipeline_seq(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
+                            int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
+    const uint64_t cap = n_bytes + 2 * n_docs + 64;
+    TK_HIP(c, c->staging.reserve(cap * 4));
+    TK_HIP(c, c->out_ids.reserve(cap * 4));
+    TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
+    TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
+    TK_HIP(c, c->block_sums.reserve((n_docs / 2048 + 4) * 8));
+    TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
+    TkEncodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bytes = d_bytes;
+    a.doc_offs = d_offs;
+    a.n_docs = n_docs;
+    a.staging = (uint32_t*)c->staging.p;
+    a.counts = (uint32_t*)c->counts.p;
+    a.work_counter = (uint32_t*)c->counters.p;
+    a.defer_count = (uint32_t*)c->counters.p + 1;
+    a.defer_list = (uint32_t*)c->defer_list.p;
+    a.add_bos = add_bos;
+    a.add_eos = add_eos;
+    a.pattern = 1;
+    a.t = c->dview;
+    c->n_flagged = 0;
+    c->n_long_docs = n_docs;
+    uint64_t total = 0;
+    TK_HIP(c, hipEventRecord(c->ev[0], s));
+    TK_HIP(c, hipEventRecord(c->ev[3], s));
+    if (n_docs) {
+        TK_HIP(c, tk_launch_iota((uint32_t*)c->defer_list.p, n_docs, s));
+        int rc = run_pass2(c, a, d_offs, (uint32_t)n_docs, s, 8192);
+        if (rc != TK_OK) return rc;
+    }
+    TK_HIP(c, hipEventRecord(c->ev[1], s));
+    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
+    TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs, (uint32_t*)c->out_ids.p, s));
+    TK_HIP(c, hipEventRecord(c->ev[2], s));
+    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+    TK_HIP(c, hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[0], c->ev[2]);
+    *n_ids = total;
+    return TK_OK;
+}
+
 // Pipeline choice: the flat pipeline, unless TK_PIPELINE=doc asks for the per-document kernels alone (tests / A-B runs).
 static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
+    if (c->pattern == 1) return run_pipeline_seq(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
     c->use_flat = c->pipeline_forced != 2;
     if (c->use_flat) return run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
     c->n_flagged = 0;

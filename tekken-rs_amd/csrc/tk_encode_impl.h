@@ -316,6 +316,106 @@ TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t p
 }
 
 // ------------------------------------------------------------------------------------------
+// SURVEY section 8 row f-3, opt-in: the `pattern` string that Mistral's tekken.json carries and the reference ignores
+// (src/tekkenizer.rs:74; literal in tests/test_small_vocab.rs:62):
+//   [^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+ | [^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*
+//   | \p{N} | ' '?[^\s\p{L}\p{N}]+[\r\n/]* | \s*[\r\n]+ | \s+(?!\S) | \s+
+// as a sequential matcher (leftmost-first alternation, greedy with backtracking), used by the piece-by-piece path of
+// pass 2 only: first version of the opt-in, every document takes that path.  Classes from unicode_tables2.h:
+// 1 U = Lu|Lt, 2 W = Ll, 3 X = Lm|Lo, 4 M, 5 N, 6 S, 0 anything else.  "Upper side" = U X M, "lower side" = W X M.
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tk_uc_class2(const TkTablesView& t, uint32_t cp) {
+    if (cp >= 0x110000u) return 0u;
+    const uint32_t blk = t.uc2_stage1[cp >> 7];
+    const uint32_t w = t.uc2_stage2[blk * 16u + ((cp & 127u) >> 3)];
+    return (w >> (4u * (cp & 7u))) & 15u;
+}
+TK_DEV uint32_t tk_class2_at(const TkTablesView& t, const uint8_t* b, uint64_t p, uint64_t n, uint32_t* len, uint32_t* cp) {
+    const uint32_t c = tk_decode_at(b, p, n, len);
+    *cp = c;
+    return tk_uc_class2(t, c);
+}
+TK_DEV bool tk_c2_upper_side(uint32_t k) { return k == 1u || k == 3u || k == 4u; }
+TK_DEV bool tk_c2_lower_side(uint32_t k) { return k == 2u || k == 3u || k == 4u; }
+
+// word of the first / second alternative that starts at p (behind the optional prefix); p itself = no match
+TK_DEV uint64_t tk_word2_at(const TkTablesView& t, const uint8_t* b, uint64_t p, uint64_t n, bool second_alt) {
+    uint64_t q = p, last_both = ~0ull;           // last char of the upper-side run that is also lower-side (X or M)
+    while (q < n) {
+        uint32_t l, c;
+        const uint32_t k = tk_class2_at(t, b, q, n, &l, &c);
+        if (!tk_c2_upper_side(k)) break;
+        if (tk_c2_lower_side(k)) last_both = q;
+        q += l;
+    }
+    uint64_t from;
+    if (second_alt) {                            // [upper side]+ [lower side]*
+        if (q == p) return p;
+        from = q;
+    } else {                                     // [upper side]* [lower side]+ : give chars back until the lower side can start
+        from = ~0ull;
+        if (q < n) {
+            uint32_t l, c;
+            if (tk_c2_lower_side(tk_class2_at(t, b, q, n, &l, &c))) from = q;
+        }
+        if (from == ~0ull) from = last_both;
+        if (from == ~0ull) return p;
+    }
+    uint64_t e = from;
+    while (e < n) {
+        uint32_t l, c;
+        if (!tk_c2_lower_side(tk_class2_at(t, b, e, n, &l, &c))) break;
+        e += l;
+    }
+    return e;
+}
+
+TK_DEV uint64_t tk_match_end2(const TkTablesView& t, const uint8_t* b, uint64_t pos, uint64_t n) {
+    uint32_t l0, c0;
+    const uint32_t k0 = tk_class2_at(t, b, pos, n, &l0, &c0);
+    const bool letter = k0 == 1u || k0 == 2u || k0 == 3u;
+    const bool prefix_ok = !(c0 == '\r' || c0 == '\n' || letter || k0 == 5u) && pos + l0 < n;
+    for (int alt = 0; alt < 2; ++alt) {          // alternatives 1 and 2: with the prefix char first, then without
+        if (prefix_ok) {
+            const uint64_t e = tk_word2_at(t, b, pos + l0, n, alt == 1);
+            if (e > pos + l0) return e;
+        }
+        const uint64_t e = tk_word2_at(t, b, pos, n, alt == 1);
+        if (e > pos) return e;
+    }
+    if (k0 == 5u) return pos + l0;               // \p{N}: one digit
+    for (int attempt = (c0 == ' ') ? 0 : 1; attempt < 2; ++attempt) {   // ' '?[^\s\p{L}\p{N}]+[\r\n/]*  (classes O and M)
+        const uint64_t p = attempt == 0 ? pos + 1 : pos;
+        uint64_t q = p;
+        while (q < n) {
+            uint32_t l, c;
+            const uint32_t k = tk_class2_at(t, b, q, n, &l, &c);
+            if (!(k == 0u || k == 4u)) break;
+            q += l;
+        }
+        if (q > p) {
+            while (q < n && (b[q] == '\r' || b[q] == '\n' || b[q] == '/')) ++q;
+            return q;
+        }
+    }
+    // the three white-space alternatives, over the maximal white-space run
+    uint64_t e = pos, after_last_nl = 0, last_char = pos;
+    bool has_nl = false;
+    while (e < n) {
+        uint32_t l, c;
+        if (tk_class2_at(t, b, e, n, &l, &c) != 6u) break;
+        last_char = e;
+        e += l;
+        if (c == '\r' || c == '\n') { has_nl = true; after_last_nl = e; }
+    }
+    if (e == pos) return pos + l0;               // (not reached for valid UTF-8)
+    if (has_nl) return after_last_nl;
+    if (e == n) return e;
+    if (last_char > pos) return last_char;
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------
 // pass 2, one piece [w0, e) of any length: whole-piece lookup (wave-wide polynomial hash for
 // pieces of >= 9 bytes), and on a miss the wave-cooperative merge over scratch memory.
 // ------------------------------------------------------------------------------------------
@@ -885,7 +985,7 @@ TK_DEV void tk_encode_doc_seq(const TkEncodeArgs& a, uint64_t d, int lane, const
     }
     uint64_t w0 = s0;
     while (w0 < s1) {
-        const uint64_t e = wv_first64(tk_match_end(t, a.bytes, w0, s1));
+        const uint64_t e = wv_first64(a.pattern ? tk_match_end2(t, a.bytes, w0, s1) : tk_match_end(t, a.bytes, w0, s1));
         tk_piece_coop(a, pw, lane, w0, e, out, cursor, scratch);
         w0 = e;
     }

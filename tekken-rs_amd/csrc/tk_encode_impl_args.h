@@ -23,6 +23,7 @@ struct TkEncodeArgs {
     uint64_t scratch_words_per_wave;
     int add_bos, add_eos;
     int split_only;
+    int pattern;                // 0: the hard-coded pattern (reference behaviour); 1: the JSON pattern of tekken.json (row f-3, pass 2 only)
     int dbg_ablate;             // timing-only ablation bits (TK_DEBUG_ABLATE): 1 skip probes, 2 skip merges, 4 skip id stores
     TkTablesView t;
 };

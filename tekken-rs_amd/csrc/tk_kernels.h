@@ -38,6 +38,8 @@ hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const 
                                    uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, hipStream_t s);
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
 
+hipError_t tk_launch_iota(uint32_t* out, uint64_t n, hipStream_t s);   // out[i] = i
+
 // ---- 18-bit wire format of ids for the multi-GPU gather (tk_kernels.hip) ----
 hipError_t tk_launch_pack18(const uint32_t* ids, uint64_t n, void* packed, uint32_t* d_bad, hipStream_t s);
 hipError_t tk_launch_unpack18(const void* packed, uint64_t n, uint32_t* ids, hipStream_t s);

@@ -329,3 +329,13 @@ hipError_t tk_launch_unpack18(const void* packed, uint64_t n, uint32_t* ids, hip
     hipLaunchKernelGGL(tk_unpack18_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, lows, highs, n, ids);
     return hipGetLastError();
 }
+
+__global__ __launch_bounds__(256) void tk_iota_kernel(uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+hipError_t tk_launch_iota(uint32_t* out, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, out, n);
+    return hipGetLastError();
+}

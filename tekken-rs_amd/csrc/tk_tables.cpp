@@ -12,6 +12,7 @@
 
 #include "../../include/tekken_hip.h"
 #include "unicode_tables.h"
+#include "unicode_tables2.h"
 
 uint32_t tk_inverse_u32(uint32_t a) {
     // Newton iteration for the inverse of an odd number modulo 2^32
@@ -30,6 +31,8 @@ TkTablesView TkHostTables::host_view() const {
     TkTablesView v;
     v.uc_stage1 = uc_stage1.data();
     v.uc_stage2 = uc_stage2.data();
+    v.uc2_stage1 = uc2_stage1.data();
+    v.uc2_stage2 = uc2_stage2.data();
     v.key8_tab = key8_tab.data();
     v.key_tab = key_tab.data();
     v.long_tab = long_tab.data();
@@ -88,6 +91,8 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
     out.blob.resize(out.blob.size() + 16, 0);  // slack so verify loops never end on the last byte
     out.uc_stage1.assign(TK_UC_STAGE1, TK_UC_STAGE1 + TK_UC_STAGE1_LEN);
     out.uc_stage2.assign(TK_UC_STAGE2, TK_UC_STAGE2 + TK_UC_STAGE2_LEN);
+    out.uc2_stage1.assign(TK_UC2_STAGE1, TK_UC2_STAGE1 + TK_UC2_STAGE1_LEN);
+    out.uc2_stage2.assign(TK_UC2_STAGE2, TK_UC2_STAGE2 + TK_UC2_STAGE2_LEN);
 
     // bytes -> rank; duplicate keys collapse in the reference's map and then fail its
     // contiguity check (src/tekkenizer.rs:801-813) => reject here as well
@@ -356,6 +361,8 @@ bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path) {
     x.key_hash_mode = h.key_hash_mode; x.n_ranks = h.n_ranks; x.num_special = h.num_special; x.bos_id = h.bos_id; x.eos_id = h.eos_id;
     x.p1inv = h.p1inv; x.p2inv = h.p2inv;
     x.n_pairs = h.n_pairs; x.n_key = h.n_key; x.n_long = h.n_long; x.n_key_second = h.n_key_second; x.n_key_spill_slots = h.n_key_spill_slots;
+    x.uc2_stage1.assign(TK_UC2_STAGE1, TK_UC2_STAGE1 + TK_UC2_STAGE1_LEN);   // constant tables, not cached
+    x.uc2_stage2.assign(TK_UC2_STAGE2, TK_UC2_STAGE2 + TK_UC2_STAGE2_LEN);
     t = std::move(x);
     return true;
 }

@@ -17,6 +17,8 @@
 struct TkTablesView {
     const uint16_t* uc_stage1;       // Unicode class trie, stage 1 (cp >> 7 -> block)
     const uint32_t* uc_stage2;       // stage 2: 16 x 2-bit classes per word
+    const uint16_t* uc2_stage1;      // class trie of the opt-in JSON pattern (row f-3): 4-bit classes O U W X M N S
+    const uint32_t* uc2_stage2;      // stage 2: 8 x 4-bit classes per word
     const tk_key8_entry* key8_tab;   // whole pieces of 2..8 bytes (exact key), cuckoo: slots h & key8_mask, alt(h) & key8_mask
     const tk_key_entry* key_tab;     // whole pieces of 9..16 bytes (exact key), cuckoo: slots h & key_mask, alt(h) & key_mask
     const tk_long_entry* long_tab;   // whole pieces of >= 17 bytes
@@ -34,6 +36,8 @@ struct TkHostTables {
     std::vector<uint32_t> offs;
     std::vector<uint16_t> uc_stage1;
     std::vector<uint32_t> uc_stage2;
+    std::vector<uint16_t> uc2_stage1;   // constant tables (unicode_tables2.h), not part of the table cache
+    std::vector<uint32_t> uc2_stage2;
     std::vector<tk_key8_entry> key8_tab;
     std::vector<tk_key_entry> key_tab;
     std::vector<tk_long_entry> long_tab;

@@ -20,7 +20,7 @@ def lib():
         L.emu_encode_batch.restype = ctypes.c_int
         L.emu_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                        u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32p,
-                                       u64p, u8p, u64p, u64p]
+                                       u64p, u8p, u64p, u64p, ctypes.c_int]
         L.emu_last_error.restype = ctypes.c_char_p
         L.emu_table_cache_roundtrip.restype = ctypes.c_int
         L.emu_table_cache_roundtrip.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
@@ -45,7 +45,7 @@ def pack_docs(docs):
     return data, offs
 
 
-def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True, split_only=False):
+def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True, split_only=False, pattern=0):
     """Runs the device algorithm on the emulator.  Returns (list of id lists, starts flags, n_deferred)."""
     toffs = np.zeros(len(token_bytes) + 1, np.uint32)
     toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
@@ -61,7 +61,7 @@ def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos
     rc = lib().emu_encode_batch(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special,
                                 bos, eos, _p(data, ctypes.c_uint8), _p(offs, ctypes.c_uint64), D, int(add_bos),
                                 int(add_eos), int(split_only), _p(out, ctypes.c_uint32), _p(oo, ctypes.c_uint64),
-                                _p(dbg, ctypes.c_uint8), ctypes.byref(ndef), ctypes.byref(nops))
+                                _p(dbg, ctypes.c_uint8), ctypes.byref(ndef), ctypes.byref(nops), int(pattern))
     if rc != 0:
         raise RuntimeError("emu_encode_batch rc=%d: %s" % (rc, lib().emu_last_error().decode()))
     ids = [out[int(oo[d]):int(oo[d + 1])].tolist() for d in range(D)]

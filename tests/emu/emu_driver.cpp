@@ -25,7 +25,7 @@ extern "C" const char* emu_last_error() { return g_err.c_str(); }
 extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
                                 uint32_t bos, uint32_t eos, const uint8_t* bytes, const uint64_t* doc_offs,
                                 uint64_t n_docs, int add_bos, int add_eos, int split_only, uint32_t* out_ids,
-                                uint64_t* out_offs, uint8_t* dbg_starts, uint64_t* n_deferred, uint64_t* n_ops) {
+                                uint64_t* out_offs, uint8_t* dbg_starts, uint64_t* n_deferred, uint64_t* n_ops, int pattern) {
     TkHostTables T;
     int rc = tk_build_tables(blob, offs, n_ranks, num_special, bos, eos, T, g_err);
     if (rc != TK_OK) return rc;
@@ -54,9 +54,16 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
     a.t = T.host_view();
 
     uint64_t ops = 0;
-    if (split_only) tkemu::run_wave([&](int lane) { tk_encode_wave<2>(a, lane, 0); });
-    else tkemu::run_wave([&](int lane) { tk_encode_wave<0>(a, lane, 0); });
-    ops += tkemu::g_wave->n_ops;
+    a.pattern = pattern;
+    if (pattern) {
+        // row f-3 (opt-in): every document takes the piece-by-piece path of pass 2 with the JSON pattern's matcher
+        for (uint64_t d = 0; d < n_docs; ++d) defer_list[d] = (uint32_t)d;
+        defer_count = (uint32_t)n_docs;
+    } else {
+        if (split_only) tkemu::run_wave([&](int lane) { tk_encode_wave<2>(a, lane, 0); });
+        else tkemu::run_wave([&](int lane) { tk_encode_wave<0>(a, lane, 0); });
+        ops += tkemu::g_wave->n_ops;
+    }
     if (n_deferred) *n_deferred = defer_count;
     if (defer_count) {
         std::vector<uint32_t> scratch_raw(5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 8, 0);

@@ -439,3 +439,44 @@ def test_bench_distributed_path_single_rank():
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["ids_total"] > 0
+
+
+def test_json_pattern_opt_in(tk, test_vocab, bench_vocab):
+    """Row f-3 (opt-in): tk_ctx_set_pattern(ctx, 1) makes the split follow the `pattern` of Mistral's tekken.json
+    (case-aware words, single digits, '/' after punctuation) -- id for id the oracle in the same mode; mode 0 afterwards
+    is the reference's behaviour again; the tokenizer level honours only the known pattern string."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "split_vectors_tekken.json")) as f:
+        g = json.load(f)
+    docs = [c["text"].encode("utf-8") for c in g["cases"]] + helpers.mixed_docs(60, 20, 80, max_len=9000) + helpers.random_unicode_docs(300) \
+        + [b"", b"HelloWorld XMLHttpRequest iPhone 1234 a/b/c\n"]
+    orc = tk_oracle.Oracle(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"])
+    orc.set_pattern(1)
+    plain = helpers.oracle_for(test_vocab)
+    e = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    e.set_pattern(1)
+    assert e.encode_docs(docs, True, True) == [orc.encode(d, True, True) for d in docs]
+    e.set_pattern(0)
+    assert e.encode_docs(docs[:200], True, False) == [plain.encode(d, True, False) for d in docs[:200]]
+    with pytest.raises(tk.TokenizerError):
+        e.set_pattern(7)
+    e.close()
+    # tokenizer level: the model file's pattern string decides
+    from test_host_tokenizer import model
+    import synth_vocab as sv
+    m = model(test_vocab["tokens"], num_special=test_vocab["num_special"], specials=("<unk>", "<s>", "</s>"))
+    m["config"]["pattern"] = sv.MISTRAL_PATTERN
+    t = tk.Tekkenizer.from_json(json.dumps(m), device=0)
+    assert t.encode("HelloWorld 12", False, False) == plain.encode(b"HelloWorld 12", False, False)      # ignored by default
+    t.set_honour_pattern(True)
+    assert t.encode("HelloWorld 12", False, False) == orc.encode(b"HelloWorld 12", False, False)
+    t.set_honour_pattern(False)
+    assert t.encode("HelloWorld 12", False, False) == plain.encode(b"HelloWorld 12", False, False)
+    t.close()
+    m["config"]["pattern"] = "something else"
+    t = tk.Tekkenizer.from_json(json.dumps(m), device=0)
+    with pytest.raises(tk.TokenizerError) as ei:
+        t.set_honour_pattern(True)
+    assert ei.value.kind == "InvalidConfig"
+    t.close()

@@ -82,3 +82,23 @@ def test_emu_long_single_piece(test_vocab):
     assert n_def == len(docs)
     for doc, g in zip(docs, got):
         assert g == o.encode(doc, True, True)
+
+
+def test_emu_json_pattern_opt_in(test_vocab):
+    """Row f-3: the device's sequential matcher for the JSON pattern of Mistral's tekken.json (tk_match_end2, pass 2),
+    on the emulator, id for id against the oracle in the same mode -- golden texts, case mixes, Unicode categories."""
+    import json
+    import os
+    import tk_oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "split_vectors_tekken.json")) as f:
+        g = json.load(f)
+    docs = [c["text"].encode("utf-8") for c in g["cases"][:400]] + [b"HelloWorld XMLHttpRequest 1234 a/b/c\n", b""]
+    o = tk_oracle.Oracle(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"])
+    o.set_pattern(1)
+    got, _, _ = emu.encode_batch(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], docs, True, True,
+                                 pattern=1)
+    for doc, ids in zip(docs, got):
+        assert ids == o.encode(doc, True, True), doc[:60]
+    # and it differs from the reference's behaviour where it should
+    plain = helpers.oracle_for(test_vocab)
+    assert plain.encode(b"HelloWorld 1234", False, False) != o.encode(b"HelloWorld 1234", False, False)

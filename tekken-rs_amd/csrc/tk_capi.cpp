@@ -352,6 +352,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.holes = (uint32_t*)c->f_flags.p + (n_docs + 1);
     fa.wave_first = (uint32_t*)c->f_wfirst.p;
     fa.t = c->dview;
+    fa.pattern = c->pattern;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
 
     // One host sync per batch in the common case.  Everything that depends on device-side counts stays on the device:
@@ -423,16 +424,25 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         a.add_bos = add_bos;
         a.add_eos = add_eos;
         a.t = c->dview;
-        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
-        const uint64_t want = ((uint64_t)n_todo + 7) / 8;
-        TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), s));
-        uint32_t n_def = 0;
-        TK_HIP(c, hipMemcpyAsync(&n_def, (uint32_t*)c->counters.p + 1, 4, hipMemcpyDeviceToHost, s));
-        TK_HIP(c, hipStreamSynchronize(s));
-        c->n_long_docs = n_def;
-        if (n_def) {
-            int rc2 = run_pass2(c, a, d_offs, n_def, s);
+        a.pattern = c->pattern;
+        if (c->pattern == 1) {
+            // JSON pattern: the handed-back documents go straight to the piece-by-piece path with its sequential matcher
+            c->n_long_docs = n_todo;
+            TK_HIP(c, hipMemcpyAsync(c->defer_list.p, c->f_todo.p, (size_t)n_todo * 4, hipMemcpyDeviceToDevice, s));   // pass 2 reads defer_list
+            int rc2 = run_pass2(c, a, d_offs, n_todo, s, 8192);
             if (rc2 != TK_OK) return rc2;
+        } else {
+            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
+            const uint64_t want = ((uint64_t)n_todo + 7) / 8;
+            TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), s));
+            uint32_t n_def = 0;
+            TK_HIP(c, hipMemcpyAsync(&n_def, (uint32_t*)c->counters.p + 1, 4, hipMemcpyDeviceToHost, s));
+            TK_HIP(c, hipStreamSynchronize(s));
+            c->n_long_docs = n_def;
+            if (n_def) {
+                int rc2 = run_pass2(c, a, d_offs, n_def, s);
+                if (rc2 != TK_OK) return rc2;
+            }
         }
         rc = finish(1);
         if (rc != TK_OK) return rc;
@@ -443,9 +453,9 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     return TK_OK;
 }
 
-// Row f-3, opt-in (tk_ctx_set_pattern(ctx, 1)): the JSON pattern of tekken.json.  First version: EVERY document takes the
-// piece-by-piece path of pass 2 with the sequential matcher tk_match_end2 (one wave per document); the flat kernel's
-// mask rules for this pattern are the next step.
+// Row f-3, opt-in (tk_ctx_set_pattern(ctx, 1)) with TK_PIPELINE=doc: EVERY document takes the piece-by-piece path of
+// pass 2 with the sequential matcher tk_match_end2 (one wave per document).  The default route for the JSON pattern is
+// the flat pipeline with tk_flat_json_kernel; this is what its handed-back documents use, and the A / B form.
 static int run_pipeline_seq(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                             int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
     const uint64_t cap = n_bytes + 2 * n_docs + 64;
@@ -494,7 +504,9 @@ static int run_pipeline_seq(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
 // Pipeline choice: the flat pipeline, unless TK_PIPELINE=doc asks for the per-document kernels alone (tests / A-B runs).
 static int run_pipeline(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
-    if (c->pattern == 1) return run_pipeline_seq(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
+    // (row f-3: TK_PIPELINE=doc selects the purely sequential form of the opt-in; the per-document window kernels only
+    // know the hard-coded pattern)
+    if (c->pattern == 1 && c->pipeline_forced == 2) return run_pipeline_seq(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
     c->use_flat = c->pipeline_forced != 2;
     if (c->use_flat) return run_pipeline_flat(c, d_bytes, d_offs, n_docs, n_bytes, add_bos, add_eos, s, n_ids);
     c->n_flagged = 0;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
 }
 
-template <int DBG, int MODE>
+template <int DBG, int MODE, int PAT = 0>
 __device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_t* lds_all) {
     const int lane = wv_lane();
     // the wave number is wave-uniform: say so, and the chunk index and everything addressed by it stay in scalar registers
@@ -63,7 +63,7 @@ __device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_
         c_end = a.n_chunks * (label + 1) / 8;
         c_step = nb * (TKF_BLOCK / 64);
     }
-    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE>(a, c, lane, lds);
+    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE, PAT>(a, c, lane, lds);
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
@@ -75,6 +75,13 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a
 __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_mode1_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
     tk_flat_kernel_body<0, 1>(a, lds_all);
+}
+
+// opt-in (row f-3): the split rules of the JSON pattern of Mistral's tekken.json
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_json_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+    if (a.t.key_hash_mode == 0u) tk_flat_kernel_body<0, 0, 1>(a, lds_all);
+    else tk_flat_kernel_body<0, 1, 1>(a, lds_all);
 }
 
 // the same kernels with the timing ablations / per-byte split flags compiled in (TK_DEBUG_ABLATE, tk_split_batch)
@@ -338,7 +345,8 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
         if (cap == 0) cap = 1280;
     }
     if (blocks > cap) blocks = cap;
-    if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    if (a.pattern == 1) hipLaunchKernelGGL(tk_flat_json_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     return hipGetLastError();

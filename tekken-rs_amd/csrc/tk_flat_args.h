@@ -47,6 +47,7 @@ struct TkFlatArgs {
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
+    int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,
                                  // 8 stop after the split rules, 16 stop after the classification
     TkTablesView t;

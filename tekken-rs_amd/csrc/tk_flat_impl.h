@@ -136,7 +136,9 @@ TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
 struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
     uint32_t U8C, LEAD, C5, BF;  // UTF-8: continuation bytes, lead bytes; C5 BF = U+017F (folds to 's')
+    uint32_t UP, SL;          // upper-case letters, '/' (the JSON pattern of row f-3 only)
     bool nmb;                 // wave-uniform: the region holds a multi-byte \p{N} char
+    bool neut;                // wave-uniform (JSON pattern): the region holds a neutral letter (Lm / Lo) or a mark
 };
 
 // 8x8 bit-matrix transpose of 8 bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte b holds bit b of every
@@ -199,7 +201,10 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     c.LEAD = p7 & p6;
     c.C5 = p7 & p6 & ~(p5 | p4 | p3) & p2 & ~p1 & p0;                           // 1100 0101
     c.BF = p7 & ~p6 & p5 & p4 & p3 & p2 & p1 & p0;                              // 1011 1111
+    c.UP = c.L & ~p5;                                                           // A..Z (letters differ in bit 5 only)
+    c.SL = p5 & ~(p7 | p6 | p4) & p3 & p2 & p1 & p0;                             // 0x2F
     c.nmb = false;
+    c.neut = false;
     return c;
 }
 
@@ -294,6 +299,78 @@ TK_DEV uint32_t tkf_rules(const TkfClass& m, uint32_t DS, int lane, uint32_t* SP
 }
 
 // ------------------------------------------------------------------------------------------
+// Row f-3: the JSON pattern of Mistral's tekken.json in lane layout (tools/flat_split_model.py flat_rules_tekken).  Scope:
+// chars of the classes upper (Lu | Lt), lower (Ll), N, \s, other; a region with a neutral letter (Lm / Lo) or a mark
+// is handed back.  Against tkf_rules: no contraction alternative; inside a letter run a piece starts at an upper-case
+// char that follows a lower-case one; every digit is a piece; the tail absorbed after a punctuation run is made of
+// CR / LF / '/' and whatever follows it starts a piece.
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tkf_rules_json(const TkfClass& m, uint32_t DS, int lane, uint32_t* SPR_out, uint32_t* cont_out) {
+    const uint32_t nDS = ~DS & TKF_WM;
+    const uint32_t DE = tkf_shr(DS, 1) | (lane == 63 ? TKF_TOPBIT : 0u);
+    const uint32_t nDE = ~DE & TKF_WM;
+#define P1(x) (tkf_shl((x), 1) & nDS)
+#define N1(x) (tkf_shr((x), 1) & nDE)
+    const uint32_t mL = m.L, mN = m.N, mS = m.S, NL = m.NL, SP = m.SP;
+    const uint32_t U8C = m.U8C, CS = TKF_WM & ~U8C;
+    const bool u8 = tkf_any(m.HI);
+    const uint32_t mO = TKF_WM & ~(mL | mN | mS);
+    const uint32_t O1 = P1(mO);
+    // the tail [\r\n/]* of a punctuation piece: begins at a CR / LF directly behind an O char, runs through CR / LF / '/'.
+    // (Several places of one run can qualify -- every CR / LF behind a '/' --: plain fixpoint, the runs are short.)
+    uint32_t ABS = NL & O1;
+    if (tkf_any(ABS)) {
+        const uint32_t R = (NL | m.SL) & nDS;
+        for (;;) {
+            const uint32_t nxt = ABS | (P1(ABS) & R);
+            const bool grew = tkf_any(nxt & ~ABS);
+            ABS = nxt;
+            if (!grew) break;
+        }
+    }
+    const uint32_t after_abs = P1(ABS) & ~ABS & CS;
+    const uint32_t Oe = mO & ~ABS;
+    const uint32_t pOS = P1(Oe | SP);
+    const uint32_t L1 = P1(mL);
+    const uint32_t Lst = mL & ~L1;
+    uint32_t X = CS & Oe & pOS;                  // an O char that is not available as a word's one-char prefix
+    if (u8) {
+        X |= P1(X) & U8C;
+        X |= P1(X) & U8C;
+        X |= P1(X) & U8C;
+    }
+    const uint32_t lower = mL & ~m.UP;
+    const uint32_t psL = (Lst & P1(mN | NL | X)) | (CS & m.UP & P1(lower));
+    const uint32_t psO = Oe & ~P1(Oe) & ~P1(SP);
+    const uint32_t psN = mN & CS;
+    const uint32_t SPR = mS & ~ABS;
+    const uint32_t cont = SPR & P1(SPR);
+    uint32_t Z = NL & SPR;
+    {
+        uint32_t C = tkf_shr(cont, 1);
+        int k = 1;
+        while (tkf_any(C) && tkf_any(Z)) {
+            Z |= tkf_shr_any(Z, k, lane) & C;
+            C &= tkf_shr_any(C, k, lane);
+            k *= 2;
+        }
+    }
+    uint32_t last = SPR & ~tkf_shr(cont, 1) & ~Z & nDE;
+    if (u8) {
+        last = (last & CS) | N1(last & U8C);
+        last = (last & CS) | N1(last & U8C);
+        last = (last & CS) | N1(last & U8C);
+        last &= CS;
+    }
+    const uint32_t psS = (SPR & ~cont) | (tkf_shl(Z, 1) & cont & ~Z) | last;
+#undef P1
+#undef N1
+    *SPR_out = SPR;
+    *cont_out = cont;
+    return psL | psN | psO | psS | after_abs | DS;
+}
+
+// ------------------------------------------------------------------------------------------
 // one chunk
 // ------------------------------------------------------------------------------------------
 // once per wave, before its first chunk: the key byte masks
@@ -319,7 +396,8 @@ TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n)
 // DBG = 0: the production instantiation.  DBG = 1 adds the timing ablations (TK_DEBUG_ABLATE) and the per-byte piece-start
 // flags of tk_split_batch: every one of those tests costs scalar registers and VALU slots the kernel does not have.
 // MODE = the key hash the tables were built with (TkTablesView::key_hash_mode), a compile-time constant here.
-template <int DBG, int MODE>
+// PAT = 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in).
+template <int DBG, int MODE, int PAT = 0>
 TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
     const int64_t n = (int64_t)a.n_bytes;
@@ -353,6 +431,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
         uint32_t* cl = lds + TKF_L_CL;
         cl[lane] = 0u; cl[64 + lane] = 0u; cl[128 + lane] = 0u;
+        if (PAT) cl[192 + lane] = 0u;               // upper-case letters
+        bool neut = false;
         if (lane == 0) {
             // the code point of a lead byte in the region's last three bytes ends beyond it: the pad word takes the real bytes
             uint32_t pad = 0u;
@@ -384,12 +464,28 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                         cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
                     }
                 }
-                const uint32_t cls = cp != 0xFFFFFFFFu ? tk_uc_class(t, cp) : TK_CLS_O;
+                uint32_t cls = TK_CLS_O;
+                bool upper = false;
+                if (cp != 0xFFFFFFFFu) {
+                    if (PAT) {
+                        // classes of unicode_tables2.h: 1 upper (Lu | Lt), 2 lower, 3 Lm | Lo, 4 mark, 5 N, 6 \s
+                        const uint32_t c2 = tk_uc_class2(t, cp);
+                        upper = c2 == 1u;
+                        cls = c2 == 1u || c2 == 2u ? TK_CLS_L : c2 == 5u ? TK_CLS_N : c2 == 6u ? TK_CLS_S : TK_CLS_O;
+                        if (c2 == 3u || c2 == 4u) neut = true;
+                    } else {
+                        cls = tk_uc_class(t, cp);
+                    }
+                }
                 if (cls != TK_CLS_O) {
                     const uint64_t bits = (uint64_t)((1u << clen) - 1u) << i;   // may reach into the next lane's word
                     wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
                     if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
                     if (cls == TK_CLS_N) nmb = true;
+                    if (PAT && upper) {
+                        wv_lds_or(cl + 192u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
+                        if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + 192u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
+                    }
                 }
             }
         }
@@ -398,6 +494,10 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         m.N |= cl[64 + lane];
         m.S |= cl[128 + lane];
         m.nmb = wv_ballot(nmb) != 0ull;
+        if (PAT) {
+            m.UP |= cl[192 + lane];
+            m.neut = wv_ballot(neut) != 0ull;
+        }
     }
     if (DBG && (a.dbg_ablate & 16)) {
         // (keeps the work alive without producing slot counts: the downstream kernels must see an empty chunk)
@@ -433,7 +533,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 
     // ---- 3. piece starts ---------------------------------------------------------------------------
     uint32_t SPR, cont;
-    const uint32_t PS = tkf_rules(m, DS, lane, &SPR, &cont);
+    const uint32_t PS = PAT ? tkf_rules_json(m, DS, lane, &SPR, &cont) : tkf_rules(m, DS, lane, &SPR, &cont);
     if (DBG && (a.dbg_ablate & 8)) {
         if (lane == 0) {
             a.kcount[c] = (PS + SPR + cont) == 0xFFFFFFFFu ? 1u : 0u;
@@ -458,15 +558,17 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 #if TKF_NHL == 2
         const uint32_t d0 = wv_readlane(DS, 0) | wv_readlane(DS, 1);
         const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0), n1 = wv_readlane(m.N, 1);
-        const uint32_t l0 = wv_readlane(m.NL, 0), l1 = wv_readlane(m.NL, 1);
+        const uint32_t tailc = PAT ? (m.NL | m.SL) : m.NL;   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
+        const uint32_t l0 = wv_readlane(tailc, 0), l1 = wv_readlane(tailc, 1);
         const bool covered = (n0 == TKF_WM && n1 == TKF_WM) || (l0 == TKF_WM && l1 == TKF_WM);
 #else
         const uint32_t d0 = wv_readlane(DS, 0);
         const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0);
-        const uint32_t l0 = wv_readlane(m.NL, 0);
+        const uint32_t l0 = wv_readlane(PAT ? (m.NL | m.SL) : m.NL, 0);   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
         const bool covered = n0 == TKF_WM || l0 == TKF_WM;
 #endif
         if (r0 > 0 && d0 == 0u && covered && lane == TKF_NHL) BAD |= 1u;
+        if (PAT && m.neut) BAD |= commit_mask;   // Lm / Lo / M chars: the sequential path takes the documents of this chunk
         // (B) a white-space run that reaches the region end, goes on in the same document and started inside
         //     the commit range
         const uint32_t top = wv_readlane(SPR, 63);

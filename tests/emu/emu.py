@@ -29,7 +29,7 @@ def lib():
         L.emu_flat_encode_batch.restype = ctypes.c_int
         L.emu_flat_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                             u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, u64p, u8p, u8p,
-                                            u64p, u64p]
+                                            u64p, u64p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -72,7 +72,7 @@ def encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos
     return ids, starts, int(ndef.value)
 
 
-def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True):
+def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, add_eos=True, pattern=0):
     """The flat path (tk_flat_impl.h) on the emulator.  Returns (id lists, starts per document, flagged list)."""
     toffs = np.zeros(len(token_bytes) + 1, np.uint32)
     toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
@@ -89,7 +89,7 @@ def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, ad
     rc = lib().emu_flat_encode_batch(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special,
                                      bos, eos, _p(data, ctypes.c_uint8), _p(offs, ctypes.c_uint64), D, int(add_bos),
                                      int(add_eos), _p(out, ctypes.c_uint32), _p(oo, ctypes.c_uint64),
-                                     _p(dbg, ctypes.c_uint8), _p(fl, ctypes.c_uint8), ctypes.byref(nfl), ctypes.byref(nops))
+                                     _p(dbg, ctypes.c_uint8), _p(fl, ctypes.c_uint8), ctypes.byref(nfl), ctypes.byref(nops), int(pattern))
     if rc != 0:
         raise RuntimeError("emu_flat_encode_batch rc=%d: %s" % (rc, lib().emu_last_error().decode()))
     ids = [out[int(oo[d]):int(oo[d + 1])].tolist() for d in range(D)]

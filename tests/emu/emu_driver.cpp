@@ -98,7 +98,7 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
 extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
                                      uint32_t bos, uint32_t eos, const uint8_t* bytes, const uint64_t* doc_offs,
                                      uint64_t n_docs, int add_bos, int add_eos, uint32_t* out_ids, uint64_t* out_offs,
-                                     uint8_t* dbg_starts, uint8_t* out_flags, uint64_t* n_flagged, uint64_t* n_ops) {
+                                     uint8_t* dbg_starts, uint8_t* out_flags, uint64_t* n_flagged, uint64_t* n_ops, int pattern) {
     TkHostTables T;
     int rc = tk_build_tables(blob, offs, n_ranks, num_special, bos, eos, T, g_err);
     if (rc != TK_OK) return rc;
@@ -129,6 +129,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.miss_count = miss_count.data();
     fa.holes = holes.data();
     fa.dbg_starts = dbg_starts;
+    fa.pattern = pattern;
     fa.t = T.host_view();
     std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
     uint64_t ops = 0;
@@ -137,7 +138,9 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             tk_flat_init_lds(fa, lds.data(), lane);
             for (uint64_t c = 0; c < n_chunks; ++c) {
                 const bool m1 = fa.t.key_hash_mode != 0u;
-                if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0>(fa, c, lane, lds.data()); }
+                if (pattern) {   // row f-3: the JSON pattern's rules (the debug flags are compiled in: split checks use them)
+                    if (m1) tk_flat_chunk<1, 1, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0, 1>(fa, c, lane, lds.data());
+                } else if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0>(fa, c, lane, lds.data()); }
                 else { if (m1) tk_flat_chunk<0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<0, 0>(fa, c, lane, lds.data()); }   // production
             }
         });
@@ -183,8 +186,14 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         a.add_bos = add_bos;
         a.add_eos = add_eos;
         a.t = T.host_view();
-        tkemu::run_wave([&](int lane) { tk_encode_wave<3>(a, lane, 0); });
-        ops += tkemu::g_wave->n_ops;
+        a.pattern = pattern;
+        if (pattern) {   // JSON pattern: the handed-back documents go straight to the piece-by-piece path
+            for (size_t i = 0; i < todo.size(); ++i) defer_list[i] = todo[i];
+            defer_count = (uint32_t)todo.size();
+        } else {
+            tkemu::run_wave([&](int lane) { tk_encode_wave<3>(a, lane, 0); });
+            ops += tkemu::g_wave->n_ops;
+        }
         if (defer_count) {
             uint64_t maxlen = 0;
             for (uint32_t i = 0; i < defer_count; ++i)

@@ -212,3 +212,63 @@ def test_emu_flat_dense_pieces(test_vocab):
     docs += [(b"q" * 70 + b",1" * 900)]                                 # a piece over 64 bytes inside a dense region
     flagged = _emu_check(test_vocab, docs)
     assert len(flagged) <= 2
+
+
+def _json_oracle(v):
+    o = tk_oracle.Oracle(v["tokens"], v["num_special"], v["bos"], v["eos"])
+    o.set_pattern(1)
+    return o
+
+
+def _emu_check_json(v, docs, bos=True, eos=True):
+    o = _json_oracle(v)
+    ids, starts, flagged = emu.flat_encode_batch(v["tokens"], v["num_special"], v["bos"], v["eos"], docs, bos, eos, pattern=1)
+    for i, d in enumerate(docs):
+        assert ids[i] == o.encode(d, bos, eos), (i, d[:80], i in flagged)
+        if i not in flagged:
+            assert starts[i] == tk_oracle.split_tekken(d), (i, d[:80])
+    return flagged
+
+
+def test_model_json_pattern():
+    """Row f-3: the JSON pattern's rules as mask algebra (tools/flat_split_model.py flat_rules_tekken) against the oracle's
+    matcher: case changes, single digits, the CR / LF / '/' tail, accented / Cyrillic letters; neutral letters defer."""
+    rng = random.Random(4)
+    alpha = list("aAbBzZ") + [" "] * 4 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　"]
+    for _ in range(400):
+        docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3]) for _ in range(rng.randint(0, rng.choice([4, 30, 200, 1500])))).encode()
+                for _ in range(rng.randint(1, 12))]
+        data = b"".join(docs)
+        offs = [0]
+        for d in docs:
+            offs.append(offs[-1] + len(d))
+        starts, deferred = fm.flat_split_chunked_tekken(data, offs, region=rng.choice([256, 2048]))
+        exp = []
+        for i, d in enumerate(docs):
+            if i not in deferred:
+                exp += [offs[i] + s for s in tk_oracle.split_tekken(d)]
+        assert starts == exp
+    _, deferred = fm.flat_split_chunked_tekken("abc 中文 def".encode() + b"Plain TextHere 12", [0, 14, 31], region=256)
+    assert deferred == {0, 1}
+
+
+def test_emu_flat_json_pattern(test_vocab):
+    """The flat kernel's JSON-pattern instantiation on the emulator, id for id against the oracle in that mode: case
+    mixes and digits on the fast path, CJK / marks handed back to the sequential matcher, long runs, region geometry."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "split_vectors_tekken.json")) as f:
+        g = json.load(f)
+    docs = [c["text"].encode("utf-8") for c in g["cases"][:500]]
+    flagged = _emu_check_json(test_vocab, docs)
+    assert 0 < len(flagged) < len(docs)
+    rng = random.Random(6)
+    alpha = list("aAbBzZxyQ") + [" "] * 5 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　", ".", ","]
+    docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 40]) for _ in range(rng.randint(0, rng.choice([4, 60, 900])))).encode()
+            for _ in range(150)]
+    docs += [("x y " * (pad // 4) + "q" * (pad % 4) + ch * rl + " Zz").encode() for pad in (1888, 1920, 1951, 1952, 1984)
+             for ch in ("\n", "/", " ", "a", "A", "!") for rl in (31, 33, 65)]
+    d, o = corpus.generate("ascii", 30, 512, seed=corpus.BASE_SEED + 1)
+    docs += corpus.docs_of(d, o)
+    flagged = _emu_check_json(test_vocab, docs)
+    assert len(flagged) < len(docs) // 2

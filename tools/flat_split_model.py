@@ -223,3 +223,185 @@ def flat_split_chunked(data: bytes, offs, region=1024, hl=32, hr=64):
         c0 += commit
     keep = sorted(s for s in starts if doc_of(s) not in deferred)
     return keep, deferred
+
+
+# ------------------------------------------------------------------------------------------
+# the JSON pattern of Mistral's tekken.json in lane layout (model of tkf_rules<PAT = 1>).
+# Scope of the fast path: chars of the classes U (Lu|Lt), W (Ll), N, S and "other"; a region that holds a neutral
+# letter (Lm / Lo: every CJK, Arabic, Hebrew ... char) or a mark (M) is handed back to the sequential path.
+# Differences to the hard-coded pattern: no contraction alternative; inside a letter run a piece starts at an upper-case
+# char that follows a lower-case one; every digit is a piece; the run absorbed after a punctuation run is made of
+# CR / LF / '/' (and whatever follows it starts a piece).
+# ------------------------------------------------------------------------------------------
+def class_masks_tekken(buf: bytes, tail: bytes = b""):
+    import tk_oracle
+    cls_fn = tk_oracle.lib().tk_oracle_class2
+    m = dict(U=0, W=0, N=0, S=0, NL=0, SP=0, SL=0, HI=0, U8C=0, NEUT=0)
+    n = len(buf)
+    ext = buf + tail[:4]
+    i = 0
+    while i < n:
+        b = ext[i]
+        bit = 1 << i
+        if b >= 0x80:
+            m["HI"] |= bit
+            if (b & 0xC0) == 0x80:
+                m["U8C"] |= bit
+                i += 1
+                continue
+            ln, cp = 1, None
+            if (b & 0xE0) == 0xC0 and i + 1 < len(ext) and (ext[i + 1] & 0xC0) == 0x80:
+                ln, cp = 2, ((b & 0x1F) << 6) | (ext[i + 1] & 0x3F)
+            elif (b & 0xF0) == 0xE0 and i + 2 < len(ext) and all((ext[i + k] & 0xC0) == 0x80 for k in (1, 2)):
+                ln, cp = 3, ((b & 0x0F) << 12) | ((ext[i + 1] & 0x3F) << 6) | (ext[i + 2] & 0x3F)
+            elif (b & 0xF8) == 0xF0 and i + 3 < len(ext) and all((ext[i + k] & 0xC0) == 0x80 for k in (1, 2, 3)):
+                ln, cp = 4, ((b & 0x07) << 18) | ((ext[i + 1] & 0x3F) << 12) | ((ext[i + 2] & 0x3F) << 6) | (ext[i + 3] & 0x3F)
+            c = cls_fn(cp) if cp is not None else 0
+            for k in range(ln):
+                if i + k < n:
+                    kb = 1 << (i + k)
+                    if c == 1:
+                        m["U"] |= kb
+                    elif c == 2:
+                        m["W"] |= kb
+                    elif c in (3, 4):
+                        m["NEUT"] |= kb
+                    elif c == 5:
+                        m["N"] |= kb
+                    elif c == 6:
+                        m["S"] |= kb
+            i += 1
+            continue
+        if 0x41 <= b <= 0x5A:
+            m["U"] |= bit
+        elif 0x61 <= b <= 0x7A:
+            m["W"] |= bit
+        elif 0x30 <= b <= 0x39:
+            m["N"] |= bit
+        elif 9 <= b <= 13 or b == 0x20:
+            m["S"] |= bit
+            if b in (10, 13):
+                m["NL"] |= bit
+            if b == 0x20:
+                m["SP"] |= bit
+        elif b == 0x2F:
+            m["SL"] |= bit
+        i += 1
+    return m
+
+
+def flat_rules_tekken(m, DS, n):
+    full = (1 << n) - 1
+    DE = (DS >> 1) | (1 << (n - 1))
+    nDS, nDE = full & ~DS, full & ~DE
+
+    def p1(x):
+        return (x << 1) & nDS & full
+
+    def n1(x):
+        return (x >> 1) & nDE
+
+    mU, mW, mN, mS, NL, SP, SL = m["U"], m["W"], m["N"], m["S"], m["NL"], m["SP"], m["SL"]
+    U8C = m.get("U8C", 0)
+    CS = full & ~U8C
+    mL = mU | mW
+    mO = full & ~(mL | mN | mS)
+    O1 = p1(mO)
+    # the run absorbed after a punctuation run: CR / LF / '/' chars, starting at a CR / LF directly behind an O char
+    # (a run of such chars can hold several places where absorption could begin -- every one that follows a '/' --, which
+    # the one-carry ripple of the hard-coded pattern's rule cannot take: plain fixpoint, the runs are short)
+    R = (NL | SL) & nDS
+    ABS = NL & O1                                   # the tail begins at a CR / LF directly behind an O char (O+ is greedy: it takes every '/')
+    while True:
+        nxt = ABS | (p1(ABS) & R)
+        if nxt == ABS:
+            break
+        ABS = nxt
+    after_abs = p1(ABS) & ~ABS                      # whatever follows the absorbed run starts a piece
+    Oe = mO & ~ABS                                  # punctuation that is not absorbed
+    pOS = p1(Oe | SP)
+    Lst = mL & ~p1(mL)
+    X = CS & Oe & pOS                               # an O char that is not available as a word's one-char prefix
+    for _ in range(3):
+        X |= p1(X) & U8C
+    psL = (Lst & p1(mN | NL)) | (Lst & p1(X)) | (CS & mU & p1(mW))
+    psO = Oe & ~p1(Oe) & ~p1(SP)
+    psN = mN & CS
+    SPR = mS & ~ABS
+    NLp = NL & SPR
+    cont = SPR & p1(SPR)
+    Z = NLp
+    C = cont >> 1
+    k = 1
+    while C and Z:
+        Z |= (Z >> k) & C
+        C &= (C >> k)
+        k *= 2
+    last = SPR & ~(cont >> 1) & ~Z & nDE
+    for _ in range(3):
+        last = (last & CS) | (n1(last & U8C))
+    psS = (SPR & ~cont) | ((Z << 1) & cont & ~Z) | (last & CS)
+    PS = (psL | psN | psO | psS | (after_abs & CS) | DS | 1) & full
+    return PS, dict(SPR=SPR, cont=cont, mN=0, NL=NL | SL)   # (the run whose coverage of the left halo hands back: CR / LF / '/')
+
+
+def flat_split_chunked_tekken(data: bytes, offs, region=2048, hl=32, hr=64):
+    """The chunked evaluation of flat_split_chunked with the JSON pattern's classes and rules; a document that touches a
+    region with a neutral letter / mark is deferred as well."""
+    import bisect
+    n = len(data)
+    commit = region - hl - hr
+    starts, deferred = set(), set()
+    doc_starts = sorted(set(int(o) for o in offs[:-1]))
+
+    def doc_of(p):
+        return bisect.bisect_right(offs, p) - 1
+
+    c0 = 0
+    while c0 < n:
+        r0, r1 = c0 - hl, c0 - hl + region
+        c1 = min(c0 + commit, n)
+        lo, hi = max(r0, 0), min(r1, n)
+        buf = bytes(data[lo:hi])
+        shift = lo - r0
+        m = {k: v << shift for k, v in class_masks_tekken(buf, bytes(data[hi:hi + 4])).items()}
+        DS = 0
+        for s in doc_starts[bisect.bisect_left(doc_starts, lo):bisect.bisect_left(doc_starts, hi)]:
+            DS |= 1 << (s - r0)
+        if hi < r1:
+            DS |= 1 << (hi - r0)
+        PS, aux = flat_rules_tekken(m, DS, region)
+        bad = 0
+        a, b = c0 - r0, c1 - r0
+        if m["NEUT"]:
+            bad |= ((1 << b) - 1) & ~((1 << a) - 1)          # every document of the commit range
+        if r0 > 0 and not (DS & 1):
+            run = aux["NL"]
+            if run & 1:
+                e = 0
+                while e < region and (run >> e) & 1 and not (e > 0 and (DS >> e) & 1):
+                    e += 1
+                if e >= a:
+                    bad |= 1 << a
+        last = region - 1
+        if r1 < n and (aux["SPR"] >> last) & 1 and not _is_start(doc_starts, r1):
+            f = last
+            while f > 0 and (aux["cont"] >> f) & 1:
+                f -= 1
+            if f < b:
+                bad |= 1 << max(f, a)
+        pos = [i for i in range(a, region) if (PS >> i) & 1] + [region]
+        for j, p in enumerate(pos[:-1]):
+            if p >= b:
+                break
+            if pos[j + 1] - p > 64:
+                bad |= 1 << p
+            starts.add(r0 + p)
+        q = 0
+        while bad >> q:
+            if (bad >> q) & 1:
+                deferred.add(doc_of(r0 + q))
+            q += 1
+        c0 += commit
+    keep = sorted(s for s in starts if doc_of(s) not in deferred)
+    return keep, deferred

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--vocab", choices=["small", "bench"], default="small")
+    ap.add_argument("--pattern", type=int, choices=[0, 1], default=0, help="1: the opt-in JSON pattern of tekken.json (row f-3)")
     a = ap.parse_args()
     import helpers
     tk = importlib.import_module("tekken-rs_amd")
@@ -28,8 +29,11 @@ def main():
         v = {"tokens": toks, "num_special": ns, "bos": bos, "eos": eos}
     else:
         v = helpers.small_trained_vocab()
-    orc = helpers.oracle_for(v)
+    import tk_oracle
+    orc = tk_oracle.Oracle(v["tokens"], v["num_special"], v["bos"], v["eos"])
+    orc.set_pattern(a.pattern)
     eng = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
+    eng.set_pattern(a.pattern)
     rng = random.Random(a.seed)
     alphabets = [
         list("abcdefghijklmnopqrstuvwxyz") + [" "] * 8 + list(".,;!?'\n"),
@@ -37,6 +41,7 @@ def main():
         list("aA bB'sS tT!\n\r\t 12"),
         ["a", "S", "1", "٣", "３", "'", "ſ", "s", "!", " ", " ", "\n", "\r", "中", "é", "\U0001f680", " ", "　", "-", "\t"],
         list("xyz") + [" "],
+        list("aAbBcCzZ") + [" "] * 4 + list("12/!-\n\r.") + ["é", "É", "Ж", "ж", "ǅ"],
         [chr(c) for c in range(32, 127)] + ["\n", "\t", "\r"],
     ]
     t0 = time.time()

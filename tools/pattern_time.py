@@ -1,4 +1,4 @@
-"""Throughput of the opt-in JSON pattern (first version: sequential piece-by-piece path) next to the
+"""Throughput of the opt-in JSON pattern (TK_PIPELINE=doc times its sequential piece-by-piece path alone) next to the
 default pipeline, on a sample of the C2 shape, with the oracle in the same mode as the checker.  Prints one JSON line."""
 import importlib
 import json

@@ -83,9 +83,8 @@ void tk_free_result(tk_result* r);
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference
  * tests/test_small_vocab.rs:62 -- instead of the pattern the reference hard-codes and always uses
- * (src/tekkenizer.rs:74,123).  mode 0 (default) = the reference's behaviour, 1 = the JSON pattern.  Text of cased
- * scripts, digits, punctuation and white space runs at the default pipeline's rate; documents that share a 2 KB region
- * with a neutral letter (\p{Lm}, \p{Lo}: CJK, Arabic ...) or a mark take a sequential piece-by-piece path (exact, slow). */
+ * (src/tekkenizer.rs:74,123).  mode 0 (default) = the reference's behaviour, 1 = the JSON pattern, on its own
+ * instantiation of the same kernels (ASCII text at the default pipeline's rate). */
 int tk_ctx_set_pattern(tk_ctx* ctx, int mode);
 
 /* Streaming / pipelined ingestion (same results as tk_encode_batch, which is what the reference's

@@ -136,9 +136,8 @@ TK_DEV uint32_t tkf_scan_excl(uint32_t v, int lane, uint32_t* total) {
 struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
     uint32_t U8C, LEAD, C5, BF;  // UTF-8: continuation bytes, lead bytes; C5 BF = U+017F (folds to 's')
-    uint32_t UP, SL;          // upper-case letters, '/' (the JSON pattern of row f-3 only)
+    uint32_t UP, SL, X, M;    // upper-case letters, '/', neutral letters (Lm | Lo), marks (the JSON pattern of row f-3 only)
     bool nmb;                 // wave-uniform: the region holds a multi-byte \p{N} char
-    bool neut;                // wave-uniform (JSON pattern): the region holds a neutral letter (Lm / Lo) or a mark
 };
 
 // 8x8 bit-matrix transpose of 8 bytes (lo = bytes 0..3, hi = bytes 4..7): afterwards byte b holds bit b of every
@@ -203,8 +202,9 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     c.BF = p7 & ~p6 & p5 & p4 & p3 & p2 & p1 & p0;                              // 1011 1111
     c.UP = c.L & ~p5;                                                           // A..Z (letters differ in bit 5 only)
     c.SL = p5 & ~(p7 | p6 | p4) & p3 & p2 & p1 & p0;                             // 0x2F
+    c.X = 0u;
+    c.M = 0u;
     c.nmb = false;
-    c.neut = false;
     return c;
 }
 
@@ -311,36 +311,78 @@ TK_DEV uint32_t tkf_rules_json(const TkfClass& m, uint32_t DS, int lane, uint32_
     const uint32_t nDE = ~DE & TKF_WM;
 #define P1(x) (tkf_shl((x), 1) & nDS)
 #define N1(x) (tkf_shr((x), 1) & nDE)
-    const uint32_t mL = m.L, mN = m.N, mS = m.S, NL = m.NL, SP = m.SP;
+    const uint32_t mL = m.L, mN = m.N, mS = m.S, NL = m.NL, SP = m.SP, mX = m.X, mM = m.M;
     const uint32_t U8C = m.U8C, CS = TKF_WM & ~U8C;
     const bool u8 = tkf_any(m.HI);
-    const uint32_t mO = TKF_WM & ~(mL | mN | mS);
-    const uint32_t O1 = P1(mO);
-    // the tail [\r\n/]* of a punctuation piece: begins at a CR / LF directly behind an O char, runs through CR / LF / '/'.
-    // (Several places of one run can qualify -- every CR / LF behind a '/' --: plain fixpoint, the runs are short.)
-    uint32_t ABS = NL & O1;
-    if (tkf_any(ABS)) {
-        const uint32_t R = (NL | m.SL) & nDS;
-        for (;;) {
-            const uint32_t nxt = ABS | (P1(ABS) & R);
-            const bool grew = tkf_any(nxt & ~ABS);
-            ABS = nxt;
-            if (!grew) break;
+    const bool marks = u8 && tkf_any(mM), neutral = u8 && tkf_any(mX | mM);
+    const uint32_t mO0 = TKF_WM & ~(mL | mX | mM | mN | mS);          // punctuation / symbols / everything else
+    // Two sets that feed each other, both decided by the char to the LEFT: T = the tail [\r\n/]* of a punctuation piece (a
+    // CR / LF behind any punctuation char, behind a mark that the 4th alternative swallowed, or behind a tail char; a '/'
+    // behind a tail char) and A = where the 4th alternative is running (a punctuation char -- not one of a tail -- behind
+    // U+0020, behind a punctuation char that is not in a tail, or behind A; a mark behind A: that alternative's class
+    // holds \p{M}).  Position i needs position i - 1 only: iterating both definitions from nothing settles chains of
+    // length k after k rounds (the chains are runs of punctuation / marks / line ends: short).
+    uint32_t T = 0u, A = 0u;
+    {
+        const uint32_t O01 = P1(mO0);
+        if (tkf_any(NL & O01) || marks) {
+            const uint32_t SP1 = P1(SP);
+            for (;;) {
+                const uint32_t T1 = P1(T);
+                const uint32_t T2 = (NL & (O01 | T1 | P1(mM & A))) | (m.SL & T1);
+                uint32_t A2 = 0u;
+                if (marks) {
+                    A2 = CS & ((mO0 & ~T2 & (SP1 | P1(mO0 & ~T2) | P1(A))) | (mM & P1(A)));   // decided at the char's first byte ...
+                    A2 |= P1(A2) & U8C;                                                      // ... and valid for all its bytes
+                    A2 |= P1(A2) & U8C;
+                    A2 |= P1(A2) & U8C;
+                }
+                const bool changed = tkf_any((T2 ^ T) | (A2 ^ A));
+                T = T2;
+                A = A2;
+                if (!changed) break;
+            }
         }
     }
-    const uint32_t after_abs = P1(ABS) & ~ABS & CS;
+    const uint32_t ABS = T;
+    const uint32_t Mabs = mM & A;                                      // marks that count as punctuation
+    const uint32_t mO = mO0 | Mabs;
+    const uint32_t neut = mX | (mM & ~Mabs);                           // upper-side AND lower-side word chars
+    const uint32_t mWd = mL | neut;                                    // word chars
+    const uint32_t after_abs = P1(ABS) & ~ABS & CS;                    // whatever follows the tail starts a piece
     const uint32_t Oe = mO & ~ABS;
     const uint32_t pOS = P1(Oe | SP);
-    const uint32_t L1 = P1(mL);
-    const uint32_t Lst = mL & ~L1;
-    uint32_t X = CS & Oe & pOS;                  // an O char that is not available as a word's one-char prefix
+    const uint32_t Wst = mWd & ~P1(mWd);                               // first byte of a word run
+    uint32_t X = CS & Oe & pOS;                                        // an O char that is not available as a word's one-char prefix
     if (u8) {
         X |= P1(X) & U8C;
         X |= P1(X) & U8C;
         X |= P1(X) & U8C;
     }
-    const uint32_t lower = mL & ~m.UP;
-    const uint32_t psL = (Lst & P1(mN | NL | X)) | (CS & m.UP & P1(lower));
+    // inside a word run: an upper-case char starts a piece when the lower side has begun (a lower-case char, then any
+    // neutral chars), and the all-upper tail of a run starts one behind a neutral char (the first alternative gives the
+    // upper-side run back down to its last neutral char when nothing lower-side follows)
+    uint32_t LW = mL & ~m.UP;
+    uint32_t psC;
+    if (neutral) {
+        for (;;) {
+            const uint32_t nxt = LW | (P1(LW) & neut);
+            const bool grew = tkf_any(nxt & ~LW);
+            LW = nxt;
+            if (!grew) break;
+        }
+        uint32_t UE = m.UP & ~N1(mWd);                                 // upper-case chars with only upper-case chars up to the run end
+        for (;;) {
+            const uint32_t nxt = UE | (N1(UE) & m.UP);
+            const bool grew = tkf_any(nxt & ~UE);
+            UE = nxt;
+            if (!grew) break;
+        }
+        psC = CS & ((m.UP & P1(LW)) | (UE & P1(neut)));
+    } else {
+        psC = CS & m.UP & P1(LW);
+    }
+    const uint32_t psL = (Wst & P1(mN | NL | X)) | psC;
     const uint32_t psO = Oe & ~P1(Oe) & ~P1(SP);
     const uint32_t psN = mN & CS;
     const uint32_t SPR = mS & ~ABS;
@@ -431,8 +473,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
         uint32_t* cl = lds + TKF_L_CL;
         cl[lane] = 0u; cl[64 + lane] = 0u; cl[128 + lane] = 0u;
-        if (PAT) cl[192 + lane] = 0u;               // upper-case letters
-        bool neut = false;
+        if (PAT) { cl[192 + lane] = 0u; cl[256 + lane] = 0u; cl[320 + lane] = 0u; }   // upper case, Lm | Lo, marks
         if (lane == 0) {
             // the code point of a lead byte in the region's last three bytes ends beyond it: the pad word takes the real bytes
             uint32_t pad = 0u;
@@ -465,27 +506,27 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                     }
                 }
                 uint32_t cls = TK_CLS_O;
-                bool upper = false;
+                uint32_t extra = 0;                      // JSON pattern: 1 upper case, 2 Lm | Lo, 3 mark -> a second mask word
                 if (cp != 0xFFFFFFFFu) {
                     if (PAT) {
                         // classes of unicode_tables2.h: 1 upper (Lu | Lt), 2 lower, 3 Lm | Lo, 4 mark, 5 N, 6 \s
                         const uint32_t c2 = tk_uc_class2(t, cp);
-                        upper = c2 == 1u;
                         cls = c2 == 1u || c2 == 2u ? TK_CLS_L : c2 == 5u ? TK_CLS_N : c2 == 6u ? TK_CLS_S : TK_CLS_O;
-                        if (c2 == 3u || c2 == 4u) neut = true;
+                        extra = c2 == 1u ? 1u : c2 == 3u ? 2u : c2 == 4u ? 3u : 0u;
                     } else {
                         cls = tk_uc_class(t, cp);
                     }
+                }
+                if (PAT && extra) {
+                    const uint64_t xb = (uint64_t)((1u << clen) - 1u) << i;
+                    wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane, (uint32_t)(xb & TKF_WM));
+                    if ((xb >> TKF_W) && lane < 63) wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane + 1u, (uint32_t)(xb >> TKF_W));
                 }
                 if (cls != TK_CLS_O) {
                     const uint64_t bits = (uint64_t)((1u << clen) - 1u) << i;   // may reach into the next lane's word
                     wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
                     if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
                     if (cls == TK_CLS_N) nmb = true;
-                    if (PAT && upper) {
-                        wv_lds_or(cl + 192u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
-                        if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + 192u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
-                    }
                 }
             }
         }
@@ -496,7 +537,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         m.nmb = wv_ballot(nmb) != 0ull;
         if (PAT) {
             m.UP |= cl[192 + lane];
-            m.neut = wv_ballot(neut) != 0ull;
+            m.X = cl[256 + lane];
+            m.M = cl[320 + lane];
         }
     }
     if (DBG && (a.dbg_ablate & 16)) {
@@ -568,7 +610,18 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         const bool covered = n0 == TKF_WM || l0 == TKF_WM;
 #endif
         if (r0 > 0 && d0 == 0u && covered && lane == TKF_NHL) BAD |= 1u;
-        if (PAT && m.neut) BAD |= commit_mask;   // Lm / Lo / M chars: the sequential path takes the documents of this chunk
+        if (PAT) {
+            // JSON pattern: two more runs whose state comes from below the region -- a word run (upper or lower side?) and a
+            // punctuation / mark run (is the 4th alternative running?) must not cover the whole left halo either
+            const uint32_t lead_cont = m.U8C & ~(m.U8C + 1u);
+            const uint32_t wd = m.L | m.X | m.M, om = (TKF_WM & ~(m.L | m.X | m.N | m.S));
+            bool cov2 = wv_readlane(wd | lead_cont, 0) == TKF_WM || wv_readlane(om | lead_cont, 0) == TKF_WM;
+#if TKF_NHL == 2
+            cov2 = (wv_readlane(wd | lead_cont, 0) == TKF_WM && wv_readlane(wd, 1) == TKF_WM) ||
+                   (wv_readlane(om | lead_cont, 0) == TKF_WM && wv_readlane(om, 1) == TKF_WM);
+#endif
+            if (r0 > 0 && d0 == 0u && cov2 && lane == TKF_NHL) BAD |= 1u;
+        }
         // (B) a white-space run that reaches the region end, goes on in the same document and started inside
         //     the commit range
         const uint32_t top = wv_readlane(SPR, 63);

@@ -232,10 +232,12 @@ def _emu_check_json(v, docs, bos=True, eos=True):
 
 def test_model_json_pattern():
     """Row f-3: the JSON pattern's rules as mask algebra (tools/flat_split_model.py flat_rules_tekken) against the oracle's
-    matcher: case changes, single digits, the CR / LF / '/' tail, accented / Cyrillic letters; neutral letters defer."""
+    matcher: case changes, single digits, the CR / LF / '/' tail, accented / Cyrillic letters, neutral letters (Lm / Lo:
+    CJK, modifier letters, ordinal indicators), marks inside words and inside punctuation runs, titlecase."""
     rng = random.Random(4)
-    alpha = list("aAbBzZ") + [" "] * 4 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　"]
-    for _ in range(400):
+    alpha = list("aAbBzZ") + [" "] * 4 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　",
+                                            "中", "文", "ʰ", "ª", "́", "̈", "ǅ", "!", ".", "\U0001f680", "¿"]
+    for _ in range(600):
         docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3]) for _ in range(rng.randint(0, rng.choice([4, 30, 200, 1500])))).encode()
                 for _ in range(rng.randint(1, 12))]
         data = b"".join(docs)
@@ -249,7 +251,7 @@ def test_model_json_pattern():
                 exp += [offs[i] + s for s in tk_oracle.split_tekken(d)]
         assert starts == exp
     _, deferred = fm.flat_split_chunked_tekken("abc 中文 def".encode() + b"Plain TextHere 12", [0, 14, 31], region=256)
-    assert deferred == {0, 1}
+    assert deferred == set()                       # neutral letters (Lo) stay on the fast path
 
 
 def test_emu_flat_json_pattern(test_vocab):
@@ -261,9 +263,10 @@ def test_emu_flat_json_pattern(test_vocab):
         g = json.load(f)
     docs = [c["text"].encode("utf-8") for c in g["cases"][:500]]
     flagged = _emu_check_json(test_vocab, docs)
-    assert 0 < len(flagged) < len(docs)
+    assert len(flagged) < len(docs) // 10          # (only the very long runs / pieces)
     rng = random.Random(6)
-    alpha = list("aAbBzZxyQ") + [" "] * 5 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　", ".", ","]
+    alpha = list("aAbBzZxyQ") + [" "] * 5 + ["1", "2", "!", "/", "-", "'", "\n", "\r", "\t", "é", "É", "Ж", "ж", "٣", "　", ".", ",",
+                                               "中", "文", "ʰ", "ª", "́", "̈", "ǅ"]
     docs = ["".join(rng.choice(alpha) * rng.choice([1, 1, 1, 2, 3, 40]) for _ in range(rng.randint(0, rng.choice([4, 60, 900])))).encode()
             for _ in range(150)]
     docs += [("x y " * (pad // 4) + "q" * (pad % 4) + ch * rl + " Zz").encode() for pad in (1888, 1920, 1951, 1952, 1984)

@@ -236,7 +236,7 @@ def flat_split_chunked(data: bytes, offs, region=1024, hl=32, hr=64):
 def class_masks_tekken(buf: bytes, tail: bytes = b""):
     import tk_oracle
     cls_fn = tk_oracle.lib().tk_oracle_class2
-    m = dict(U=0, W=0, N=0, S=0, NL=0, SP=0, SL=0, HI=0, U8C=0, NEUT=0)
+    m = dict(U=0, W=0, N=0, S=0, NL=0, SP=0, SL=0, HI=0, U8C=0, X=0, M=0)
     n = len(buf)
     ext = buf + tail[:4]
     i = 0
@@ -264,8 +264,10 @@ def class_masks_tekken(buf: bytes, tail: bytes = b""):
                         m["U"] |= kb
                     elif c == 2:
                         m["W"] |= kb
-                    elif c in (3, 4):
-                        m["NEUT"] |= kb
+                    elif c == 3:
+                        m["X"] |= kb
+                    elif c == 4:
+                        m["M"] |= kb
                     elif c == 5:
                         m["N"] |= kb
                     elif c == 6:
@@ -301,30 +303,64 @@ def flat_rules_tekken(m, DS, n):
     def n1(x):
         return (x >> 1) & nDE
 
+    def fix_right(seed, through):            # seed plus everything reachable to the right through `through`
+        a = seed
+        while True:
+            b = a | (p1(a) & through)
+            if b == a:
+                return a
+            a = b
+
+    def fix_left(seed, through):
+        a = seed
+        while True:
+            b = a | (n1(a) & through)
+            if b == a:
+                return a
+            a = b
+
     mU, mW, mN, mS, NL, SP, SL = m["U"], m["W"], m["N"], m["S"], m["NL"], m["SP"], m["SL"]
+    mX, mM = m.get("X", 0), m.get("M", 0)
     U8C = m.get("U8C", 0)
     CS = full & ~U8C
-    mL = mU | mW
-    mO = full & ~(mL | mN | mS)
-    O1 = p1(mO)
-    # the run absorbed after a punctuation run: CR / LF / '/' chars, starting at a CR / LF directly behind an O char
-    # (a run of such chars can hold several places where absorption could begin -- every one that follows a '/' --, which
-    # the one-carry ripple of the hard-coded pattern's rule cannot take: plain fixpoint, the runs are short)
-    R = (NL | SL) & nDS
-    ABS = NL & O1                                   # the tail begins at a CR / LF directly behind an O char (O+ is greedy: it takes every '/')
-    while True:
-        nxt = ABS | (p1(ABS) & R)
-        if nxt == ABS:
-            break
-        ABS = nxt
-    after_abs = p1(ABS) & ~ABS                      # whatever follows the absorbed run starts a piece
-    Oe = mO & ~ABS                                  # punctuation that is not absorbed
+    mO0 = full & ~(mU | mW | mX | mM | mN | mS)          # punctuation / symbols / everything else
+    # Two sets that feed each other, both decided by the char to the LEFT: T = the tail [\\r\\n/]* of a punctuation piece
+    # (a CR / LF behind any punctuation char, behind a mark that the 4th alternative swallowed, or behind a tail char; a '/'
+    # behind a tail char) and A = where the 4th alternative is running (a punctuation char -- not one of a tail -- behind
+    # U+0020, behind a punctuation char that is not in a tail, or behind A; a mark behind A: the class of the 4th
+    # alternative holds \\p{M}).  A mark in A counts as punctuation, every other mark is a word char.  Position i needs
+    # position i - 1 only, so iterating the two definitions from nothing settles chains of length k after k rounds.
+    T, A = 0, 0
+    if (NL & p1(mO0)) or mM:
+        while True:
+            T2 = (NL & p1(mO0 | T | (mM & A))) | (SL & p1(T))
+            A2 = CS & ((mO0 & ~T2 & (p1(SP) | p1(mO0 & ~T2) | p1(A))) | (mM & p1(A)))   # decided at the char's first byte ...
+            for _ in range(3):
+                A2 |= p1(A2) & U8C                                                       # ... and valid for all its bytes
+            if T2 == T and A2 == A:
+                break
+            T, A = T2, A2
+    ABS = T
+    Mabs = mM & A
+    mO = mO0 | Mabs
+    neut = mX | (mM & ~Mabs)                               # upper-side AND lower-side chars
+    mWd = mU | mW | neut                                   # word chars
+    after_abs = p1(ABS) & ~ABS
+    Oe = mO & ~ABS
     pOS = p1(Oe | SP)
-    Lst = mL & ~p1(mL)
-    X = CS & Oe & pOS                               # an O char that is not available as a word's one-char prefix
+    Wst = mWd & ~p1(mWd)                                   # first byte of a word run
+    X = CS & Oe & pOS                                      # an O char that is not available as a word's one-char prefix
     for _ in range(3):
         X |= p1(X) & U8C
-    psL = (Lst & p1(mN | NL)) | (Lst & p1(X)) | (CS & mU & p1(mW))
+    # inside a word run: an upper-case char starts a piece when the lower side has begun (a lower-case char, then any
+    # neutral chars), and the all-upper tail of a run starts one behind a neutral char (the first alternative gives the
+    # upper-side run back down to its last neutral char when nothing lower-side follows)
+    LW = fix_right(mW, neut) if neut else mW
+    psC = CS & mU & p1(LW)
+    if neut:
+        UE = fix_left(mU & ~n1(mWd), mU)                   # upper-case chars with only upper-case chars up to the run end
+        psC |= CS & UE & p1(neut)
+    psL = (Wst & p1(mN | NL)) | (Wst & p1(X)) | psC
     psO = Oe & ~p1(Oe) & ~p1(SP)
     psN = mN & CS
     SPR = mS & ~ABS
@@ -342,7 +378,7 @@ def flat_rules_tekken(m, DS, n):
         last = (last & CS) | (n1(last & U8C))
     psS = (SPR & ~cont) | ((Z << 1) & cont & ~Z) | (last & CS)
     PS = (psL | psN | psO | psS | (after_abs & CS) | DS | 1) & full
-    return PS, dict(SPR=SPR, cont=cont, mN=0, NL=NL | SL)   # (the run whose coverage of the left halo hands back: CR / LF / '/')
+    return PS, dict(SPR=SPR, cont=cont, mN=0, NL=NL | SL, WD=mWd, OM=mO0 | mM)
 
 
 def flat_split_chunked_tekken(data: bytes, offs, region=2048, hl=32, hr=64):
@@ -373,16 +409,17 @@ def flat_split_chunked_tekken(data: bytes, offs, region=2048, hl=32, hr=64):
         PS, aux = flat_rules_tekken(m, DS, region)
         bad = 0
         a, b = c0 - r0, c1 - r0
-        if m["NEUT"]:
-            bad |= ((1 << b) - 1) & ~((1 << a) - 1)          # every document of the commit range
         if r0 > 0 and not (DS & 1):
-            run = aux["NL"]
-            if run & 1:
-                e = 0
-                while e < region and (run >> e) & 1 and not (e > 0 and (DS >> e) & 1):
-                    e += 1
-                if e >= a:
-                    bad |= 1 << a
+            # runs whose state comes from below the region: the CR / LF / '/' tail, a word run (upper or lower side?)
+            # and a punctuation / mark run (is the 4th alternative running?) must not cover the whole left halo
+            lead_cont = m["U8C"] & ~(m["U8C"] + 1)
+            for run in (aux["NL"], aux["WD"] | lead_cont, aux["OM"] | lead_cont):
+                if run & 1:
+                    e = 0
+                    while e < region and (run >> e) & 1 and not (e > 0 and (DS >> e) & 1):
+                        e += 1
+                    if e >= a:
+                        bad |= 1 << a
         last = region - 1
         if r1 < n and (aux["SPR"] >> last) & 1 and not _is_start(doc_starts, r1):
             f = last

@@ -41,7 +41,7 @@ def main():
         list("aA bB'sS tT!\n\r\t 12"),
         ["a", "S", "1", "٣", "３", "'", "ſ", "s", "!", " ", " ", "\n", "\r", "中", "é", "\U0001f680", " ", "　", "-", "\t"],
         list("xyz") + [" "],
-        list("aAbBcCzZ") + [" "] * 4 + list("12/!-\n\r.") + ["é", "É", "Ж", "ж", "ǅ"],
+        list("aAbBcCzZ") + [" "] * 4 + list("12/!-\n\r.") + ["é", "É", "Ж", "ж", "ǅ", "中", "文", "ʰ", "ª", "́", "̈", "\U0001f680", "¿", "—"],
         [chr(c) for c in range(32, 127)] + ["\n", "\t", "\r"],
     ]
     t0 = time.time()

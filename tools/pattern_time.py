@@ -20,11 +20,12 @@ def main():
     toks, ns, bos, eos = sv.load_tokens(sv.ensure_default())
     eng = tk.Engine(toks, ns, bos, eos, device=0)
     n_docs = int(os.environ.get("N_DOCS", "200000"))
-    data, offs = corpus.generate("ascii", n_docs, 512, seed=corpus.BASE_SEED + 1)
+    kind, doc_len = os.environ.get("KIND", "ascii"), int(os.environ.get("DOC_LEN", "512"))
+    data, offs = corpus.generate(kind, n_docs, doc_len, seed=corpus.BASE_SEED + (1 if kind == "ascii" else 2))
     import torch
     d_bytes = torch.from_numpy(data).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
-    out = {"what": "opt-in JSON pattern vs default", "docs": n_docs, "bytes": int(offs[-1])}
+    out = {"what": "opt-in JSON pattern vs default", "kind": kind, "docs": n_docs, "bytes": int(offs[-1])}
     for mode in (0, 1):
         eng.set_pattern(mode)
         ms = []
@@ -44,8 +45,9 @@ def main():
         eids, eoo = orc.encode_batch(data[:int(offs[m])], offs[:m + 1], True, True, threads=1)
         cpu_s = time.perf_counter() - t0
         key = "json_pattern" if mode else "default"
+        handed = eng.last_stats()["handed_back"]
         out[key] = {"ms": round(float(np.median(ms)), 3), "MBps": round(int(offs[-1]) / 1e6 / (float(np.median(ms)) * 1e-3), 1),
-                    "ids": int(len(ids)), "bit_exact_vs_oracle_sample": bool(np.array_equal(oo[:m + 1], eoo) and np.array_equal(ids[:int(oo[m])], eids)),
+                    "ids": int(len(ids)), "handed_back_docs": handed, "bit_exact_vs_oracle_sample": bool(np.array_equal(oo[:m + 1], eoo) and np.array_equal(ids[:int(oo[m])], eids)),
                     "cpu_oracle_MBps_1_thread": round(int(offs[m]) / 1e6 / cpu_s, 1)}
     print(json.dumps(out))
 

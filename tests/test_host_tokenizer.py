@@ -243,3 +243,11 @@ def test_model_cache_from_file(tk, small_vocab, bench_vocab, tmp_path, monkeypat
     print("from_file host-only: parse %.3f s, from cache %.3f s" % (t1 - t0, t2 - t1))
     assert a.vocab_size() == b.vocab_size() and a.id_to_piece(100000) == b.id_to_piece(100000)
     assert (t2 - t1) < (t1 - t0)
+
+
+def test_honour_pattern_needs_device_and_known_pattern(tk, small):
+    """Row f-3 at the tokenizer level: the opt-in exists only for a device-backed object (the pattern is applied by the
+    kernels); a host-only object refuses it loudly."""
+    with pytest.raises(tk.TokenizerError) as e:
+        small.set_honour_pattern(True)
+    assert e.value.kind in ("NoDevice", "Tokenizers", "InvalidConfig")

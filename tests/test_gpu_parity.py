@@ -387,6 +387,8 @@ def test_dense_piece_regions(tk, eng_small, test_vocab):
             b"x" * 40 + b"1,2," * 600 + b" zzzzzz " + b"3;4;" * 500]
     docs += [b"7," * rng.randint(1, 40) for _ in range(2000)]
     docs += [(b"q" * 70 + b",1" * 900)]
+    # piece counts of a region sweeping across the capacity of the LDS list (1 054): a dense stretch of a bytes, then sparse text
+    docs += [b"1," * a + b"abcdefgh " * 300 for a in range(480, 560)]
     orc = helpers.oracle_for(test_vocab)
     data, offs = tk.pack_docs(docs)
     check_batch(eng_small, orc, data, offs)

@@ -2,6 +2,9 @@
 //
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
 //   tk_flat_kernel            split + lookup of one region (64 x TKF_W bytes) per wave, ids chunk-dense
+//   tk_flat_mode1_kernel      the same for tables built with the strong key hash; tk_flat_json_kernel: the split rules of the
+//                             JSON pattern of tekken.json (opt-in); tk_flat_dbg_kernel: timing
+//                             ablations / per-byte split flags compiled in
 //   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
 //   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32-wide register arrays / one lane per byte)
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel
@@ -9,7 +12,7 @@
 //   tk_flat_assemble_kernel   chunk-dense ids -> packed ids in document order with BOS / EOS
 //                             (reference src/tekkenizer.rs:390-402)
 //
-// Integer / byte work, no MFMA; bound: HBM (DESIGN.md has the byte accounting).
+// Integer / byte work, no MFMA; roofline: HBM by the byte accounting of DESIGN.md, in practice VALU issue (section 6).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

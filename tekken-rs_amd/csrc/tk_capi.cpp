@@ -53,7 +53,7 @@ struct tk_ctx {
     std::string err;
     TkHostTables host;
     TkTablesView dview;
-    DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_blob, t_offs, t_spblob, t_spoffs, t_uc2a, t_uc2b;
+    DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_pairf, t_blob, t_offs, t_spblob, t_spoffs, t_uc2a, t_uc2b;
     int pattern = 0;               // tk_ctx_set_pattern: 0 the reference's hard-coded pattern, 1 the JSON pattern (row f-3)
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
@@ -142,6 +142,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         (rc = upload(c, c->t_long, h.long_tab.data(), h.long_tab.size() * sizeof(tk_long_entry))) ||
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
         (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
+        (rc = upload(c, c->t_pairf, h.pair_filter.data(), h.pair_filter.size() * 4)) ||
         (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())) ||
         (rc = upload(c, c->t_offs, h.offs.data(), h.offs.size() * 4)))
         return fail(rc);
@@ -155,6 +156,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview.long_tab = (const tk_long_entry*)c->t_long.p;
     c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
     c->dview.pair2 = (const uint32_t*)c->t_pair2.p;
+    c->dview.pair_filter = (const uint32_t*)c->t_pairf.p;
     c->dview.blob = (const uint8_t*)c->t_blob.p;
 
     if (c->counters.reserve(64) != hipSuccess) { c->err = "hipMalloc(counters) failed"; return fail(TK_ERR_RUNTIME); }
@@ -180,7 +182,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_blob, &c->t_offs,
+    DevBuf* bufs[] = {&c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,

@@ -179,6 +179,39 @@ TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, ui
     }
 }
 
+TK_DEV uint32_t tk_probe_pair_f(const TkTablesView& t, const uint32_t* filt, uint32_t a, uint32_t b) {
+    const uint32_t f = tk_pair_fbit(tk_pair_hash(a, b));
+    return ((filt[f >> 5] >> (f & 31u)) & 1u) ? tk_probe_pair(t, a, b) : TK_RANK_MAX;
+}
+
+// the merge kernels' form: either probe may be unwanted, and `filt` (the PAIR filter, tk_hash.h, in LDS there) lets a
+// probe whose bit is clear skip its gather -- the pair is in no bucket
+TK_DEV void tk_probe_pair_x2f(const TkTablesView& t, const uint32_t* filt, bool want0, uint32_t a0, uint32_t b0, bool want1,
+                              uint32_t a1, uint32_t b1, uint32_t& r0, uint32_t& r1) {
+    const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
+    const uint32_t h0 = tk_pair_hash(a0, b0), h1 = tk_pair_hash(a1, b1);
+    const uint32_t f0 = tk_pair_fbit(h0), f1 = tk_pair_fbit(h1);
+    const uint32_t w0 = filt[f0 >> 5], w1 = filt[f1 >> 5];
+    const bool m0 = want0 && ((w0 >> (f0 & 31u)) & 1u), m1 = want1 && ((w1 >> (f1 & 31u)) & 1u);
+    tk_u64x2 p0, p1;
+    p0.x = p0.y = p1.x = p1.y = TK_PAIR_EMPTY;
+    if (m0) p0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h0 & t.pair_mask));
+    if (m1) p1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h1 & t.pair_mask));
+    WV_PIN(p0.x); WV_PIN(p0.y); WV_PIN(p1.x); WV_PIN(p1.y);
+    r0 = tk_pair_in(p0, key0);
+    r1 = tk_pair_in(p1, key1);
+    const bool n0 = r0 == TK_RANK_MAX && tk_pair_spilled(p0), n1 = r1 == TK_RANK_MAX && tk_pair_spilled(p1);
+    if (n0 || n1) {
+        tk_u64x2 q0, q1;
+        q0.x = q0.y = q1.x = q1.y = TK_PAIR_EMPTY;
+        if (n0) q0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h0) & t.pair_mask));
+        if (n1) q1 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (tk_hash_alt(h1) & t.pair_mask));
+        WV_PIN(q0.x); WV_PIN(q0.y); WV_PIN(q1.x); WV_PIN(q1.y);
+        if (n0) r0 = tk_pair_in(q0, key0);
+        if (n1) r1 = tk_pair_in(q1, key1);
+    }
+}
+
 TK_DEV uint32_t tk_wave_sum(uint32_t v, int lane) {
     for (int d = 1; d < 64; d <<= 1) v += wv_shfl(v, lane ^ d);
     return v;

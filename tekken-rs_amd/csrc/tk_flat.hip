@@ -6,7 +6,7 @@
 //                             JSON pattern of tekken.json (opt-in); tk_flat_dbg_kernel: timing
 //                             ablations / per-byte split flags compiled in
 //   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
-//   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32-wide register arrays / one lane per byte)
+//   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (parts in LDS columns / one lane per byte)
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel
 //   tk_flat_counts_kernel     ids per document from the chunk prefix sums and the document-start ranks
 //   tk_flat_assemble_kernel   chunk-dense ids -> packed ids in document order with BOS / EOS
@@ -104,19 +104,43 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uin
     for (uint64_t w = (lo + 63) / 64; w * 64 < hi; ++w) wave_first[w] = (uint32_t)e;
 }
 
-// persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are)
-__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
-    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
-    const uint64_t total = a.miss_prefix[2 * a.n_chunks];
-    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane());
+// persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are).
+// Every block keeps the PAIR filter (64 KB, tk_hash.h) in LDS: the kernels are bound by the rate of the PAIR probes'
+// gathers, and a probe whose filter bit is clear issues none.
+template <int THREADS>
+TK_DEV void tk_merge_load_filter(const TkFlatArgs& a, uint32_t* filt) {
+    const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(a.t.pair_filter);
+    for (uint32_t i = threadIdx.x; i < TK_PAIRF_WORDS / 4; i += THREADS) reinterpret_cast<tk_u32x4*>(filt)[i] = src[i];
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
-    const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
+// LDS per block: the filter (64 KB), then every wave's part columns (tk_merge_lds: 8 KB / 16 KB).  One block per CU.
+#ifndef TKM_BLOCK
+#define TKM_BLOCK 768        /* 12 waves: 64 KB + 12 x 8 KB = 160 KB */
+#endif
+#ifndef TKM_WIDE_BLOCK
+#define TKM_WIDE_BLOCK 384   /* 6 waves: 64 KB + 6 x 16 KB = 160 KB */
+#endif
+#define TKM_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_BLOCK / 64) * TKM_LDS_WORDS(16)) * 4)
+#define TKM_WIDE_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_WIDE_BLOCK / 64) * TKM_LDS_WORDS(32)) * 4)
+__global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
+    extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
+    tk_merge_load_filter<TKM_BLOCK>(a, wlds);
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKM_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_BLOCK / 64);
+    const uint64_t total = a.miss_prefix[2 * a.n_chunks];
+    uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(16);
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane(), mlds, wlds);
+}
+
+__global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
+    extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
+    tk_merge_load_filter<TKM_WIDE_BLOCK>(a, wlds);
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKM_WIDE_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_WIDE_BLOCK / 64);
     const uint64_t total = a.miss_prefix[4 * a.n_chunks] - a.miss_prefix[2 * a.n_chunks];
-    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<true>(a, w, wv_lane());
+    uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(32);
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<true>(a, w, wv_lane(), mlds, wlds);
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
@@ -357,15 +381,30 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
 
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
-    // persistent grids (the number of queued pieces stays on the device); never more blocks than sub-queues could fill
-    const uint64_t cap = 16384;   // many more blocks than are resident: the rounds a wave needs vary, small units balance better
-    uint64_t b1 = (a.n_chunks * 4 + 3) / 4, b2 = (a.n_chunks + 3) / 4;
-    if (b1 > cap) b1 = cap;
-    if (b2 > cap / 2) b2 = cap / 2;
+    // persistent grids (the number of queued pieces stays on the device): the blocks that are resident at once -- each
+    // one copies the PAIR filter into its LDS first -- and never more than the sub-queues could fill
+    static uint64_t res1 = 0, res2 = 0;
+    if (res1 == 0) {
+        int dev = 0, cus = 256, p1 = 0, p2 = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tk_merge_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TKM_WIDE_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(tk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TKM_LDS_BYTES) != hipSuccess)
+            return hipErrorInvalidValue;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p1, tk_merge_kernel, TKM_BLOCK, TKM_LDS_BYTES) != hipSuccess || p1 <= 0) p1 = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, tk_merge_wide_kernel, TKM_WIDE_BLOCK, TKM_WIDE_LDS_BYTES) != hipSuccess || p2 <= 0) p2 = 1;
+        res1 = (uint64_t)cus * (uint64_t)p1;
+        res2 = (uint64_t)cus * (uint64_t)p2;
+    }
+    uint64_t b1 = (a.n_chunks * 4 + TKM_BLOCK / 64 - 1) / (TKM_BLOCK / 64), b2 = (a.n_chunks + TKM_WIDE_BLOCK / 64 - 1) / (TKM_WIDE_BLOCK / 64);
+    if (b1 > res1) b1 = res1;
+    if (b2 > res2) b2 = res2;
     hipLaunchKernelGGL(tk_merge_wavefirst_kernel, dim3(tkf_blocks(2 * a.n_chunks)), dim3(TKF_BLOCK), 0, s, a.miss_prefix,
                        2 * a.n_chunks, a.wave_first);
-    hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKF_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKF_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKM_BLOCK), TKM_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKM_WIDE_BLOCK), TKM_WIDE_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

@@ -872,14 +872,16 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 #define TKM_SHORT 16
 
 template <bool WIDE>
-TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane);
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* mlds, const uint32_t* filt);
 
 // 64 queued pieces per wave.  The queue counts are laid out class-major ([k * n_chunks + c]); their exclusive prefix
 // sums (total at [4 n_chunks]) order all queued pieces by class first, chunk second: item i lives in the sub-queue e
 // with prefix[e] <= i < prefix[e + 1].  WIDE = false takes the items of the classes 2..8 / 9..16 bytes, WIDE = true
 // those of 17..32 / 33..64 bytes (own kernel: its 32-wide register arrays would cost the common case occupancy).
+// mlds: TKM_LDS_WORDS(32 if WIDE, else 16) words of LDS of the wave's own; filt: the block's LDS copy of the PAIR
+// filter (TK_PAIRF_WORDS words, tk_hash.h)
 template <bool WIDE>
-TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
+TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* mlds, const uint32_t* filt) {
     const uint64_t* prefix = a.miss_prefix;
     const uint64_t n_e = 4 * a.n_chunks;
     const uint64_t first = WIDE ? prefix[2 * a.n_chunks] : 0, total = WIDE ? prefix[n_e] : prefix[2 * a.n_chunks];
@@ -955,13 +957,13 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane) {
         const uint32_t off = k == 0 ? TKF_MISSOFF0 : k == 1 ? TKF_MISSOFF1 : k == 2 ? TKF_MISSOFF2 : TKF_MISSOFF3;
         rec = a.miss_list[chunk * TKF_MISSCAP + off + (item - pcl)];
     }
-    tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane);
+    tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
 // sequential merge of one piece per lane, parts in registers: N-wide arrays, every loop unrolled so that they are
 // only ever indexed statically; predication does the rest.  `kk` = the piece bytes, np = number of bytes.
 template <int N>
-TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* kk, uint32_t len, uint32_t* out) {
+TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, const uint32_t* filt, bool mine, const uint32_t* kk, uint32_t len, uint32_t* out) {
     uint32_t np = mine ? len : 0u;
     uint32_t tk[N], pr[N];
 #pragma unroll
@@ -998,9 +1000,7 @@ TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* 
                 np -= 1;
                 const bool has_next = bi + 1 < np, has_prev = bi > 0;
                 uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
-                if (has_next && has_prev) tk_probe_pair_x2(t, best, tn, tp, best, r_next, r_prev);
-                else if (has_next) r_next = tk_probe_pair(t, best, tn);
-                else if (has_prev) r_prev = tk_probe_pair(t, tp, best);
+                tk_probe_pair_x2f(t, filt, has_next, best, tn, has_prev, tp, best, r_next, r_prev);
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     if ((uint32_t)i == bi) { tk[i] = best; pr[i] = r_next; }
@@ -1017,8 +1017,101 @@ TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, bool mine, const uint32_t* 
     return mine ? len - np : 0u;
 }
 
+// sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of two
+// N x 64 word arrays (word i * 64 + l, so whatever positions the lanes index, a wave's access is free of bank
+// conflicts, and no lane ever touches another one's words: no barrier).  Parts never move: bit i of `alive` says that
+// a part starts at byte i, tok[i] is its id and key[i] = (rank of the pair (part i, its successor) << 5) | i, or all
+// ones -- so the leftmost smallest rank is one unsigned minimum over the column (v_min3: half an instruction per
+// entry), and a merge is a handful of bit operations and five LDS accesses.  The register variant (tk_merge_regs)
+// shifts whole arrays by predication instead: ~3x (N = 16) to ~4x (N = 32) the VALU issues per merge, which is
+// what bounded these kernels.
+#define TKM_LDS_WORDS(N) (2 * (N) * 64)
+#ifdef TKM_ABLATE   /* timing-only experiments on the merge kernels (never defined in the shipped build) */
+#define TKM_AB(a, bit) (((a).dbg_ablate & (bit)) != 0)
+#else
+#define TKM_AB(a, bit) false
+#endif
+template <int N>
+TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool mine, const uint32_t* kk, uint32_t len,
+                             uint32_t* out, uint32_t* mlds, int lane) {
+    const TkTablesView& t = a.t;
+    uint32_t* tokc = mlds + lane;
+    uint32_t* keyc = mlds + N * 64 + lane;
+    const uint32_t n = mine ? len : 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t b = (kk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t b1 = i + 1 < N ? (kk[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : 0u;
+        uint32_t key = 0xFFFFFFFFu;
+        if ((uint32_t)(i + 1) < n && !TKM_AB(a, 2048)) {
+            const uint32_t r = t.pair2[b | (b1 << 8)];
+            if (r != TK_RANK_MAX) key = (r << 5) | (uint32_t)i;
+        }
+        tokc[i * 64] = b;
+        keyc[i * 64] = key;
+    }
+    uint32_t alive = n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    bool active = mine && !TKM_AB(a, 1024);
+    while (wv_ballot(active)) {
+        if (active) {
+            uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < N - 1; ++i) {
+                const uint32_t k = keyc[i * 64];
+                best = k < best ? k : best;
+            }
+            if (best == 0xFFFFFFFFu) {
+                active = false;
+            } else {
+                // the parts at bi and at the next live position j become one part (at bi) whose id is the rank
+                const uint32_t bi = best & 31u, rank = best >> 5;
+                const uint32_t above = alive & ~((2u << bi) - 1u);            // bi <= N - 2
+                const uint32_t j = (uint32_t)__builtin_ctz(above);            // exists: key[bi] was a pair
+                const uint32_t above2 = above & (above - 1u);
+                const uint32_t below = alive & ((1u << bi) - 1u);
+                const bool has_next = above2 != 0u, has_prev = below != 0u;
+                const uint32_t k = has_next ? (uint32_t)__builtin_ctz(above2) : 0u;
+                const uint32_t p = has_prev ? 31u - (uint32_t)__builtin_clz(below) : 0u;
+                const uint32_t tn = tokc[k * 64], tp = tokc[p * 64];
+                alive &= ~(1u << j);
+                tokc[bi * 64] = rank;
+                keyc[j * 64] = 0xFFFFFFFFu;
+                uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
+                tk_probe_pair_x2f(t, filt, has_next, rank, tn, has_prev, tp, rank, r_next, r_prev);
+                keyc[bi * 64] = r_next == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_next << 5) | bi);
+                if (has_prev) keyc[p * 64] = r_prev == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_prev << 5) | p);
+            }
+        }
+    }
+    const uint32_t np = (uint32_t)__builtin_popcount(alive);
+    if (mine && !TKM_AB(a, 256)) {
+        // the piece's `len` slots: its np ids, then holes -- gathered into registers and stored four at a time (the cost
+        // of a scattered store is per lane and instruction, not per byte), single words only for the last len % 4
+        uint32_t rem = alive;
+        uint32_t v[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const uint32_t pos = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
+            const uint32_t id = tokc[pos * 64] + t.num_special;
+            v[q] = (uint32_t)q < np ? id : TKF_HOLE;
+            rem &= rem - 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < N; q += 4) {
+            if ((uint32_t)q + 4u <= len) {
+                wv_store16(out + q, v[q], v[q + 1], v[q + 2], v[q + 3]);
+            } else {
+                if ((uint32_t)q < len) out[q] = v[q];
+                if ((uint32_t)q + 1u < len) out[q + 1] = v[q + 1];
+                if ((uint32_t)q + 2u < len) out[q + 2] = v[q + 2];
+            }
+        }
+    }
+    return mine ? len - np : 0u;
+}
+
 template <bool WIDE>
-TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane) {
+TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* mlds, const uint32_t* filt) {
     const TkTablesView& t = a.t;
     const uint32_t pos = TKF_REC_POS(rec), len = TKF_REC_LEN(rec), slot = TKF_REC_SLOT(rec);
     const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
@@ -1041,10 +1134,10 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
         }
         if (!WIDE) {
             const bool s8 = inregs && len <= 8u, s16 = inregs && len > 8u;
-            if (wv_ballot(s8)) holes += tk_merge_regs<8>(t, s8, kk, len, out);
-            if (wv_ballot(s16)) holes += tk_merge_regs<16>(t, s16, kk, len, out);
+            if (wv_ballot(s8)) holes += tk_merge_lds<8>(a, filt, s8, kk, len, out, mlds, lane);
+            if (wv_ballot(s16)) holes += tk_merge_lds<16>(a, filt, s16, kk, len, out, mlds, lane);
         } else {
-            if (wv_ballot(inregs)) holes += tk_merge_regs<32>(t, inregs, kk, len, out);
+            if (wv_ballot(inregs)) holes += tk_merge_lds<32>(a, filt, inregs, kk, len, out, mlds, lane);
         }
     }
 
@@ -1084,7 +1177,7 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
             const bool has_next = na < pe;
             const uint32_t tn = wv_shfl(tok, na < 64 ? na : lane);
             const bool need = tk_bit(A, lane) && (winner || (has_next && tk_bit(Wm, na)));
-            if (need) prank = has_next ? tk_probe_pair(t, tok, tn) : TK_RANK_MAX;
+            if (need) prank = has_next ? tk_probe_pair_f(t, filt, tok, tn) : TK_RANK_MAX;
         }
         const uint32_t k = (uint32_t)tk_popc64(A);
         if (inmiss && tk_bit(A, lane)) pout[tk_popc64(A & tk_lowmask(lane))] = tok + t.num_special;
@@ -1093,12 +1186,26 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
     }
 
     // ---- the document of the piece loses `holes` ids ---------------------------------------------------
-    if (have && holes) {
+    // Queued pieces are in text order inside a sub-queue, so neighbouring lanes mostly share their document: the
+    // counts of a run of lanes with the same document are summed in the wave (one scan) and its last lane does the
+    // one atomic -- 64 atomics on two or three addresses serialise in the L2.
+    if (wv_ballot(have && holes != 0u) && !TKM_AB(a, 512)) {
         // largest d with doc_offs[d] <= g: the documents from first_doc[chunk] - 1 on start at or above the region
-        uint64_t d = a.first_doc[chunk];
-        d = d > 0 ? d - 1 : 0;
-        while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
-        wv_atomic_add(a.holes + d, holes);
+        uint64_t d = 0;
+        if (have) {
+            d = a.first_doc[chunk];
+            d = d > 0 ? d - 1 : 0;
+            while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
+        }
+        const uint32_t key = have ? (uint32_t)d : 0xFFFFFFFFu;             // (documents are numbered below 2^32 - 1)
+        const uint32_t kprev = wv_shfl(key, lane > 0 ? lane - 1 : 0), knext = wv_shfl(key, lane < 63 ? lane + 1 : 63);
+        const bool head = lane == 0 || kprev != key, tail = lane == 63 || knext != key;
+        const uint64_t HEADS = wv_ballot(head);
+        const uint32_t P = wv_scan_incl_u32(have ? holes : 0u);
+        const int start = tk_msb64(HEADS & (tk_lowmask(lane) | (1ull << lane)));      // the head of this lane's run
+        const uint32_t before = wv_shfl(P, start > 0 ? start - 1 : 0);
+        const uint32_t sum = P - (start > 0 ? before : 0u);
+        if (have && tail && sum) wv_atomic_add(a.holes + d, sum);
     }
 }
 

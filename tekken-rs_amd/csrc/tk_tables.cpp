@@ -27,6 +27,16 @@ static uint32_t pow2_at_least(uint64_t n) {
     return c;
 }
 
+void TkHostTables::make_pair_filter() {
+    pair_filter.assign(TK_PAIRF_WORDS, 0u);
+    for (uint64_t e : pair_tab) {
+        if (e == TK_PAIR_EMPTY) continue;
+        const uint64_t key = tk_pair_key(e);
+        const uint32_t b = tk_pair_fbit(tk_pair_hash((uint32_t)(key >> TK_ID_BITS), (uint32_t)(key & ((1u << TK_ID_BITS) - 1u))));
+        pair_filter[b >> 5] |= 1u << (b & 31u);
+    }
+}
+
 TkTablesView TkHostTables::host_view() const {
     TkTablesView v;
     v.uc_stage1 = uc_stage1.data();
@@ -38,6 +48,7 @@ TkTablesView TkHostTables::host_view() const {
     v.long_tab = long_tab.data();
     v.pair_tab = pair_tab.data();
     v.pair2 = pair2.data();
+    v.pair_filter = pair_filter.data();
     v.blob = blob.data();
     v.key8_mask = key8_mask;
     v.key_mask = key_mask;
@@ -273,6 +284,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         }
         for (uint64_t b1 : spill) out.pair_tab[2 * b1] |= TK_PAIR_SPILL;   // (a bucket that spilled is full: its first entry is real)
     }
+    out.make_pair_filter();
     return TK_OK;
 }
 
@@ -363,6 +375,7 @@ bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path) {
     x.n_pairs = h.n_pairs; x.n_key = h.n_key; x.n_long = h.n_long; x.n_key_second = h.n_key_second; x.n_key_spill_slots = h.n_key_spill_slots;
     x.uc2_stage1.assign(TK_UC2_STAGE1, TK_UC2_STAGE1 + TK_UC2_STAGE1_LEN);   // constant tables, not cached
     x.uc2_stage2.assign(TK_UC2_STAGE2, TK_UC2_STAGE2 + TK_UC2_STAGE2_LEN);
+    x.make_pair_filter();
     t = std::move(x);
     return true;
 }

@@ -24,6 +24,7 @@ struct TkTablesView {
     const tk_long_entry* long_tab;   // whole pieces of >= 17 bytes
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
+    const uint32_t* pair_filter;     // [TK_PAIRF_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab (tk_hash.h)
     const uint8_t* blob;             // token bytes, for verifying LONG hits
     uint32_t key8_mask, key_mask, long_mask, pair_mask;
     uint32_t key_hash_mode;          // tk_key_hash mode the KEY table was built with
@@ -43,12 +44,14 @@ struct TkHostTables {
     std::vector<tk_long_entry> long_tab;
     std::vector<uint64_t> pair_tab;
     std::vector<uint32_t> pair2;
+    std::vector<uint32_t> pair_filter;  // derived from pair_tab (make_pair_filter), not part of the table cache
     uint32_t key8_mask = 0, key_mask = 0, long_mask = 0, pair_mask = 0, key_hash_mode = 0;
     uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
     uint32_t p1inv = 0, p2inv = 0;
     uint64_t n_pairs = 0, n_key = 0, n_long = 0, n_key_second = 0, n_key_spill_slots = 0;
 
     TkTablesView host_view() const;
+    void make_pair_filter();
 };
 
 // Returns 0 on success; on failure returns a negative TK_ERR_* code and fills `err`.

@@ -84,6 +84,14 @@ TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) {
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
 }
 
+// four consecutive words to an address that is only word-aligned (one global_store_dwordx4 per lane)
+TK_DEV void wv_store16(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) u32x4_w;
+    u32x4_w v;
+    v.x = a; v.y = b; v.z = c; v.w = d;
+    *reinterpret_cast<u32x4_w*>(p) = v;
+}
+
 // inclusive prefix sum over the 64 lanes: DPP row shifts inside the rows of 16, then the two row broadcasts
 // (lanes without a source read 0) -- VALU only, no LDS crossbar
 TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {

@@ -153,12 +153,13 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         for (uint64_t e = 0; e < 2 * n_chunks; ++e)
             for (uint64_t w = (mpfx[e] + 63) / 64; w * 64 < mpfx[e + 1]; ++w) wave_first[w] = (uint32_t)e;
         fa.wave_first = wave_first.data();
+        std::vector<uint32_t> mlds(TKM_LDS_WORDS(32), 0xDEADBEEFu);
         for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane); });
+            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data(), fa.t.pair_filter); });
             ops += tkemu::g_wave->n_ops;
         }
         for (uint64_t w = 0; w * 64 < n_wide; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane); });
+            tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane, mlds.data(), fa.t.pair_filter); });
             ops += tkemu::g_wave->n_ops;
         }
     }

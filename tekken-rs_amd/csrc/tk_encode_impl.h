@@ -180,6 +180,7 @@ TK_DEV void tk_probe_pair_x2(const TkTablesView& t, uint32_t a0, uint32_t b0, ui
 }
 
 TK_DEV uint32_t tk_probe_pair_f(const TkTablesView& t, const uint32_t* filt, uint32_t a, uint32_t b) {
+    if (!filt) return tk_probe_pair(t, a, b);
     const uint32_t f = tk_pair_fbit(tk_pair_hash(a, b));
     return ((filt[f >> 5] >> (f & 31u)) & 1u) ? tk_probe_pair(t, a, b) : TK_RANK_MAX;
 }
@@ -191,8 +192,12 @@ TK_DEV void tk_probe_pair_x2f(const TkTablesView& t, const uint32_t* filt, bool 
     const uint64_t key0 = ((uint64_t)a0 << TK_ID_BITS) | (uint64_t)b0, key1 = ((uint64_t)a1 << TK_ID_BITS) | (uint64_t)b1;
     const uint32_t h0 = tk_pair_hash(a0, b0), h1 = tk_pair_hash(a1, b1);
     const uint32_t f0 = tk_pair_fbit(h0), f1 = tk_pair_fbit(h1);
-    const uint32_t w0 = filt[f0 >> 5], w1 = filt[f1 >> 5];
-    const bool m0 = want0 && ((w0 >> (f0 & 31u)) & 1u), m1 = want1 && ((w1 >> (f1 & 31u)) & 1u);
+    bool m0 = want0, m1 = want1;
+    if (filt) {
+        const uint32_t w0 = filt[f0 >> 5], w1 = filt[f1 >> 5];
+        m0 = m0 && ((w0 >> (f0 & 31u)) & 1u);
+        m1 = m1 && ((w1 >> (f1 & 31u)) & 1u);
+    }
     tk_u64x2 p0, p1;
     p0.x = p0.y = p1.x = p1.y = TK_PAIR_EMPTY;
     if (m0) p0 = *reinterpret_cast<const tk_u64x2*>(t.pair_tab + 2u * (h0 & t.pair_mask));

@@ -105,8 +105,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uin
 }
 
 // persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are).
-// Every block keeps the PAIR filter (64 KB, tk_hash.h) in LDS: the kernels are bound by the rate of the PAIR probes'
-// gathers, and a probe whose filter bit is clear issues none.
+// Every block keeps the PAIR filter (tk_hash.h) in LDS: a probe whose filter bit is clear issues no gather.
 template <int THREADS>
 TK_DEV void tk_merge_load_filter(const TkFlatArgs& a, uint32_t* filt) {
     const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(a.t.pair_filter);
@@ -114,23 +113,27 @@ TK_DEV void tk_merge_load_filter(const TkFlatArgs& a, uint32_t* filt) {
     __syncthreads();
 }
 
-// LDS per block: the filter (64 KB), then every wave's part columns (tk_merge_lds: 8 KB / 16 KB).  One block per CU.
+// LDS per block: the filter (32 KB), then every wave's part columns (tk_merge_lds: 8 KB / 16 KB).  One block per CU.
 #ifndef TKM_BLOCK
-#define TKM_BLOCK 768        /* 12 waves: 64 KB + 12 x 8 KB = 160 KB */
+#define TKM_BLOCK 1024       /* 16 waves: 32 KB + 16 x 8 KB = 160 KB */
 #endif
 #ifndef TKM_WIDE_BLOCK
-#define TKM_WIDE_BLOCK 384   /* 6 waves: 64 KB + 6 x 16 KB = 160 KB */
+#define TKM_WIDE_BLOCK 512   /* 8 waves: 32 KB + 8 x 16 KB = 160 KB */
 #endif
-#define TKM_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_BLOCK / 64) * TKM_LDS_WORDS(16)) * 4)
+#ifndef TKM_FILTER
+#define TKM_FILTER 1
+#endif
+#define TKM_FWORDS (TKM_FILTER ? TK_PAIRF_WORDS : 0u)
+#define TKM_LDS_BYTES ((TKM_FWORDS + (TKM_BLOCK / 64) * TKM_LDS_WORDS(16)) * 4)
 #define TKM_WIDE_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_WIDE_BLOCK / 64) * TKM_LDS_WORDS(32)) * 4)
 __global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
-    tk_merge_load_filter<TKM_BLOCK>(a, wlds);
+    if (TKM_FILTER) tk_merge_load_filter<TKM_BLOCK>(a, wlds);
     const uint64_t wave = (uint64_t)blockIdx.x * (TKM_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_BLOCK / 64);
     const uint64_t total = a.miss_prefix[2 * a.n_chunks];
-    uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(16);
-    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane(), mlds, wlds);
+    uint32_t* mlds = wlds + TKM_FWORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(16);
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane(), mlds, TKM_FILTER ? wlds : nullptr);
 }
 
 __global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes

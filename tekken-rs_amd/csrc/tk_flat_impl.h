@@ -863,8 +863,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 // ------------------------------------------------------------------------------------------
 // tk_merge_wave: byte-pair merge of 64 queued pieces, ONE LANE PER PIECE (tiktoken's _byte_pair_merge,
 // repeatedly merge the leftmost minimum-rank adjacent pair).  Every lane runs its own
-// chain of dependent PAIR probes, 64 chains per wave and many waves per SIMD hide their latency.
-// Pieces of up to TKM_SHORT bytes keep their parts in registers; the rare longer
+// chain of dependent PAIR probes, 64 chains per wave and several waves per SIMD hide their latency.
+// Pieces of up to 32 bytes keep their parts in LDS columns of the lane's own (tk_merge_lds); the rare longer
 // ones (<= 64 bytes) are merged one at a time, one lane per byte, with the segmented-min rounds.
 // The ids go to the `len` slots the flat kernel reserved; unused slots become TKF_HOLE and the
 // document's hole count is raised so that tk_flat_counts / assemble can squeeze them out.
@@ -877,7 +877,7 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
 // 64 queued pieces per wave.  The queue counts are laid out class-major ([k * n_chunks + c]); their exclusive prefix
 // sums (total at [4 n_chunks]) order all queued pieces by class first, chunk second: item i lives in the sub-queue e
 // with prefix[e] <= i < prefix[e + 1].  WIDE = false takes the items of the classes 2..8 / 9..16 bytes, WIDE = true
-// those of 17..32 / 33..64 bytes (own kernel: its 32-wide register arrays would cost the common case occupancy).
+// those of 17..32 / 33..64 bytes (own kernel: its 32-entry LDS columns would cost the common case occupancy).
 // mlds: TKM_LDS_WORDS(32 if WIDE, else 16) words of LDS of the wave's own; filt: the block's LDS copy of the PAIR
 // filter (TK_PAIRF_WORDS words, tk_hash.h)
 template <bool WIDE>
@@ -960,71 +960,14 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint3
     tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
-// sequential merge of one piece per lane, parts in registers: N-wide arrays, every loop unrolled so that they are
-// only ever indexed statically; predication does the rest.  `kk` = the piece bytes, np = number of bytes.
-template <int N>
-TK_DEV uint32_t tk_merge_regs(const TkTablesView& t, const uint32_t* filt, bool mine, const uint32_t* kk, uint32_t len, uint32_t* out) {
-    uint32_t np = mine ? len : 0u;
-    uint32_t tk[N], pr[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) tk[i] = (kk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        pr[i] = TK_RANK_MAX;
-        if (i + 1 < N && (uint32_t)(i + 1) < np) pr[i] = t.pair2[tk[i] | (tk[(i + 1) & (N - 1)] << 8)];
-    }
-    bool active = mine;
-    while (wv_ballot(active)) {
-        if (active) {
-            // leftmost minimum; pr[i] == MAX for i >= np - 1 is an invariant
-            uint32_t best = TK_RANK_MAX, bi = 0;
-#pragma unroll
-            for (int i = 0; i < N - 1; ++i) {
-                if (pr[i] < best) { best = pr[i]; bi = (uint32_t)i; }
-            }
-            if (best == TK_RANK_MAX) {
-                active = false;
-            } else {
-                // parts bi and bi + 1 become one part whose id is the rank of the pair
-                uint32_t tn = 0, tp = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    if ((uint32_t)i == bi + 2u) tn = tk[i];
-                    if ((uint32_t)i + 1u == bi) tp = tk[i];
-                }
-#pragma unroll
-                for (int i = 0; i < N - 1; ++i) {
-                    if ((uint32_t)i > bi) { tk[i] = tk[i + 1]; pr[i] = pr[i + 1]; }
-                }
-                pr[N - 1] = TK_RANK_MAX;
-                np -= 1;
-                const bool has_next = bi + 1 < np, has_prev = bi > 0;
-                uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
-                tk_probe_pair_x2f(t, filt, has_next, best, tn, has_prev, tp, best, r_next, r_prev);
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    if ((uint32_t)i == bi) { tk[i] = best; pr[i] = r_next; }
-                    if ((uint32_t)i + 1u == bi) pr[i] = r_prev;
-                }
-            }
-        }
-    }
-    if (mine) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if ((uint32_t)i < len) out[i] = (uint32_t)i < np ? tk[i] + t.num_special : TKF_HOLE;
-    }
-    return mine ? len - np : 0u;
-}
-
 // sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of two
 // N x 64 word arrays (word i * 64 + l, so whatever positions the lanes index, a wave's access is free of bank
 // conflicts, and no lane ever touches another one's words: no barrier).  Parts never move: bit i of `alive` says that
 // a part starts at byte i, tok[i] is its id and key[i] = (rank of the pair (part i, its successor) << 5) | i, or all
 // ones -- so the leftmost smallest rank is one unsigned minimum over the column (v_min3: half an instruction per
-// entry), and a merge is a handful of bit operations and five LDS accesses.  The register variant (tk_merge_regs)
-// shifts whole arrays by predication instead: ~3x (N = 16) to ~4x (N = 32) the VALU issues per merge, which is
-// what bounded these kernels.
+// entry), and a merge is a handful of bit operations and five LDS accesses.  (Parts in N-wide register arrays,
+// shifted by predication -- the first form of this -- cost ~3x (N = 16) to ~4x (N = 32) the VALU issues per merge
+// and 95 / 153 VGPRs.)
 #define TKM_LDS_WORDS(N) (2 * (N) * 64)
 #ifdef TKM_ABLATE   /* timing-only experiments on the merge kernels (never defined in the shipped build) */
 #define TKM_AB(a, bit) (((a).dbg_ablate & (bit)) != 0)
@@ -1118,7 +1061,7 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
     uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
     uint32_t holes = 0;
 
-    // ---- pieces of up to 32 bytes: one lane each, parts in registers (8- / 16- / 32-wide by class) ------
+    // ---- pieces of up to 32 bytes: one lane each, parts in LDS columns (8 / 16 / 32 entries by class) ------
     {
         const uint32_t cap = WIDE ? 32u : TKM_SHORT;
         const bool inregs = have && len <= cap;

@@ -94,10 +94,13 @@ TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
     return tk_fmix32(a * 0x9E3779B1u + b * 0x85EBCA77u + 0x165667B1u);
 }
 
-/* PAIR filter: one bit per tk_pair_hash value of a stored pair (bit tk_pair_fbit(h) of a 2^TK_PAIRF_LOG2-bit map, 64 KB:
-   the merge kernels keep it in LDS).  A clear bit proves that the pair is in no bucket, so the probe's gather -- the
-   cost that bounds those kernels -- is not issued; a set bit proves nothing. */
-#define TK_PAIRF_LOG2 19
+/* PAIR filter: one bit per tk_pair_hash value of a stored pair (bit tk_pair_fbit(h) of a 2^TK_PAIRF_LOG2-bit map, 32 KB:
+   the merge kernels keep it in LDS).  A clear bit proves that the pair is in no bucket, so the probe's gather is not
+   issued; a set bit proves nothing.  (Measured, DESIGN.md section 6: 64 KB halves the false positives but costs the
+   merge kernels four waves per CU, and the waves are worth more.) */
+#ifndef TK_PAIRF_LOG2
+#define TK_PAIRF_LOG2 18
+#endif
 #define TK_PAIRF_WORDS (1u << (TK_PAIRF_LOG2 - 5))
 TK_HD uint32_t tk_pair_fbit(uint32_t h) { return h >> (32 - TK_PAIRF_LOG2); }
 

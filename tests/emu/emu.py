@@ -105,12 +105,13 @@ def table_info(token_bytes, num_special):
     toffs = np.zeros(len(token_bytes) + 1, np.uint32)
     toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
     blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
-    out = np.zeros(6, np.uint64)
+    out = np.zeros(9, np.uint64)
     rc = lib().emu_table_info(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special, _p(out, ctypes.c_uint64))
     if rc != 0:
         raise RuntimeError("emu_table_info rc=%d: %s" % (rc, lib().emu_last_error().decode()))
     return dict(key_hash_mode=int(out[0]), key8_slots=int(out[1]), key16_slots=int(out[2]), keys_in_second_slot=int(out[3]),
-                flagged_slots=int(out[4]), pair_buckets=int(out[5]))
+                flagged_slots=int(out[4]), pair_buckets=int(out[5]), pairs=int(out[6]), pair_filter_set_bits=int(out[7]),
+                pair_filter_bits=int(out[8]))
 
 
 def table_cache_roundtrip(token_bytes, num_special, path):

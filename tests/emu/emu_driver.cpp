@@ -256,6 +256,20 @@ extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_
     if (rc != TK_OK) return rc;
     out[0] = T.key_hash_mode; out[1] = (uint64_t)T.key8_mask + 1; out[2] = (uint64_t)T.key_mask + 1;
     out[3] = T.n_key_second; out[4] = T.n_key_spill_slots; out[5] = (uint64_t)T.pair_mask + 1;
+    // PAIR filter (tk_hash.h): every stored pair must have its bit set (a clear bit is taken as proof of absence);
+    // out[6] = pairs, out[7] = set bits, out[8] = filter bits
+    if (T.pair_filter.size() != TK_PAIRF_WORDS) { g_err = "pair filter size"; return TK_ERR_RUNTIME; }
+    uint64_t n_pairs = 0, n_set = 0;
+    for (uint64_t e : T.pair_tab) {
+        if (e == TK_PAIR_EMPTY) continue;
+        ++n_pairs;
+        const uint64_t key = tk_pair_key(e);
+        const uint32_t b = tk_pair_fbit(tk_pair_hash((uint32_t)(key >> TK_ID_BITS), (uint32_t)(key & ((1u << TK_ID_BITS) - 1u))));
+        if (b >= (1u << TK_PAIRF_LOG2) || !((T.pair_filter[b >> 5] >> (b & 31u)) & 1u)) { g_err = "a stored pair is missing from the PAIR filter"; return TK_ERR_RUNTIME; }
+    }
+    for (uint32_t w : T.pair_filter) n_set += (uint64_t)__builtin_popcount(w);
+    if (n_pairs != T.n_pairs || n_set > n_pairs) { g_err = "pair filter counts"; return TK_ERR_RUNTIME; }
+    out[6] = n_pairs; out[7] = n_set; out[8] = 1ull << TK_PAIRF_LOG2;
     return TK_OK;
 }
 
@@ -279,7 +293,7 @@ extern "C" int emu_table_cache_roundtrip(const uint8_t* blob, const uint32_t* of
     auto same = [](const auto& x, const auto& y) { return x.size() == y.size() && (x.empty() || memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0); };
     if (!(same(A.blob, B.blob) && same(A.offs, B.offs) && same(A.uc_stage1, B.uc_stage1) && same(A.uc_stage2, B.uc_stage2) &&
           same(A.key8_tab, B.key8_tab) && same(A.key_tab, B.key_tab) && same(A.long_tab, B.long_tab) && same(A.pair_tab, B.pair_tab) &&
-          same(A.pair2, B.pair2) && A.key8_mask == B.key8_mask && A.key_mask == B.key_mask && A.long_mask == B.long_mask &&
+          same(A.pair2, B.pair2) && same(A.pair_filter, B.pair_filter) && A.key8_mask == B.key8_mask && A.key_mask == B.key_mask && A.long_mask == B.long_mask &&
           A.pair_mask == B.pair_mask && A.key_hash_mode == B.key_hash_mode && A.n_ranks == B.n_ranks && A.num_special == B.num_special &&
           A.bos_id == B.bos_id && A.eos_id == B.eos_id && A.p1inv == B.p1inv && A.p2inv == B.p2inv && A.n_pairs == B.n_pairs)) {
         g_err = "loaded tables differ from the built ones";

@@ -275,3 +275,17 @@ def test_emu_flat_json_pattern(test_vocab):
     docs += corpus.docs_of(d, o)
     flagged = _emu_check_json(test_vocab, docs)
     assert len(flagged) < len(docs) // 2
+
+
+def test_pair_filter_has_no_false_negatives(test_vocab, small_vocab):
+    """The merge kernels take a clear bit of the PAIR filter (csrc/tk_hash.h) as proof that a pair is in no bucket and
+    skip the probe: every stored pair must have its bit set, for the table as built and as reloaded from the cache
+    (emu_table_info / emu_table_cache_roundtrip check it pair by pair and compare the two filters)."""
+    import tempfile
+    for v in (test_vocab, small_vocab):
+        info = emu.table_info(v["tokens"], v["num_special"])
+        assert info["pair_filter_set_bits"] <= info["pairs"] and (info["pairs"] == 0) == (info["pair_filter_set_bits"] == 0)
+        assert info["pair_filter_bits"] >= 1 << 15
+    assert emu.table_info(test_vocab["tokens"], test_vocab["num_special"])["pairs"] > 0
+    with tempfile.TemporaryDirectory() as d:
+        emu.table_cache_roundtrip(test_vocab["tokens"], test_vocab["num_special"], d + "/t.bin")

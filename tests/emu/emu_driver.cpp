@@ -153,13 +153,24 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         for (uint64_t e = 0; e < 2 * n_chunks; ++e)
             for (uint64_t w = (mpfx[e] + 63) / 64; w * 64 < mpfx[e + 1]; ++w) wave_first[w] = (uint32_t)e;
         fa.wave_first = wave_first.data();
-        std::vector<uint32_t> mlds(TKM_LDS_WORDS(32), 0xDEADBEEFu);
+        // the wave's LDS columns sit between two guard zones: a write outside the kernel's share (8 KB narrow, 16 KB
+        // wide) would be silent on the device
+        const size_t G = 256;
+        std::vector<uint32_t> mlds(G + TKM_LDS_WORDS(32) + G, 0xDEADBEEFu);
+        auto guards_ok = [&](size_t used) {
+            for (size_t i = 0; i < G; ++i)
+                if (mlds[i] != 0xDEADBEEFu || mlds[G + used + i] != 0xDEADBEEFu) return false;
+            return true;
+        };
         for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data(), fa.t.pair_filter); });
+            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
+            if (!guards_ok(TKM_LDS_WORDS(16))) { g_err = "tk_merge_wave<false> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
         for (uint64_t w = 0; w * 64 < n_wide; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane, mlds.data(), fa.t.pair_filter); });
+            std::fill(mlds.begin(), mlds.end(), 0xDEADBEEFu);
+            tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
+            if (!guards_ok(TKM_LDS_WORDS(32))) { g_err = "tk_merge_wave<true> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
     }
@@ -274,6 +285,7 @@ extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_
 }
 
 // table cache (row f-2): build, save, load, compare field by field; out = {build seconds, save seconds, load seconds, file bytes}
+#include <algorithm>
 #include <chrono>
 extern "C" int emu_table_cache_roundtrip(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
                                          const char* path, double* out) {

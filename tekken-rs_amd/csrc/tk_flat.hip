@@ -386,10 +386,15 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     // persistent grids (the number of queued pieces stays on the device): the blocks that are resident at once -- each
     // one copies the PAIR filter into its LDS first -- and never more than the sub-queues could fill
-    static uint64_t res1 = 0, res2 = 0;
+    // (per device: a process may hold contexts on several GPUs, and the LDS opt-in is a per-device function attribute;
+    // two threads racing through the first call on a device compute the same values)
+    static uint64_t res1_dev[64] = {0}, res2_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint64_t& res1 = res1_dev[dev & 63];
+    uint64_t& res2 = res2_dev[dev & 63];
     if (res1 == 0) {
-        int dev = 0, cus = 256, p1 = 0, p2 = 0;
-        (void)hipGetDevice(&dev);
+        int cus = 256, p1 = 0, p2 = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(tk_merge_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TKM_WIDE_LDS_BYTES) != hipSuccess ||
@@ -398,8 +403,8 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
             return hipErrorInvalidValue;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p1, tk_merge_kernel, TKM_BLOCK, TKM_LDS_BYTES) != hipSuccess || p1 <= 0) p1 = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, tk_merge_wide_kernel, TKM_WIDE_BLOCK, TKM_WIDE_LDS_BYTES) != hipSuccess || p2 <= 0) p2 = 1;
-        res1 = (uint64_t)cus * (uint64_t)p1;
         res2 = (uint64_t)cus * (uint64_t)p2;
+        res1 = (uint64_t)cus * (uint64_t)p1;
     }
     uint64_t b1 = (a.n_chunks * 4 + TKM_BLOCK / 64 - 1) / (TKM_BLOCK / 64), b2 = (a.n_chunks + TKM_WIDE_BLOCK / 64 - 1) / (TKM_WIDE_BLOCK / 64);
     if (b1 > res1) b1 = res1;

@@ -21,7 +21,10 @@ def lib():
         so = os.path.join(_HERE, "libtk_corpus.so")
         src = os.path.join(_HERE, "corpus_gen.c")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", so, src, "-lm", "-lpthread"])
+            # (several ranks may get here at once: build under a private name, publish with an atomic rename)
+            tmp = "%s.tmp%d" % (so, os.getpid())
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", tmp, src, "-lm", "-lpthread"])
+            os.replace(tmp, so)
         L = ctypes.CDLL(so)
         u64p = ctypes.POINTER(ctypes.c_uint64)
         u8p = ctypes.POINTER(ctypes.c_uint8)

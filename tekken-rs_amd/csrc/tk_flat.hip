@@ -170,7 +170,8 @@ __device__ __forceinline__ uint64_t tkf_G(const uint64_t* doc_offs, uint64_t i, 
 // per document: where its id slots start in the chunk-dense buffer, how many there are (holes included) and how many of
 // them lie in the first chunk -- everything tk_flat_assemble_kernel needs in one 16-byte load
 struct alignas(16) TkFlatDocInfo {
-    uint64_t src;      // index into tmp (or into the per-document kernel's staging for a handed-back document)
+    uint64_t src;      // (chunk << 32) | first slot inside the chunk's row of tmp -- no division by the row stride in the
+                       // assembly; for a handed-back document the index into the per-document kernel's staging
     uint32_t n_slots;  // slots to walk (handed-back document: ids to copy)
     uint32_t n_first;  // slots in the first chunk; bit 31: not eligible for the two-segment fast copy; 0xFFFFFFFF marks a
                        // handed-back document
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_
     if (p < n_bytes) {
         const uint64_t c = p / TKF_COMMIT;
         const uint64_t in_chunk = P[c + 1] - g0;  // slots of chunk c from the document start on
-        di.src = c * TKF_STRIDE + lstart[d];
+        di.src = (c << 32) | (uint64_t)lstart[d];
         di.n_first = (uint32_t)(in_chunk < (g1 - g0) ? in_chunk : (g1 - g0));
         // the assembly's prefetching copy takes documents of <= 128 slots that lie in at most two chunks
         const uint64_t rest = (g1 - g0) - di.n_first;
@@ -255,8 +256,8 @@ __device__ __forceinline__ void tkf_assemble_doc(const TkFlatAssembleArgs& a, co
     // the document's slots: n_first in its first chunk, then whole chunks (slot 0 on) until n_slots are walked;
     // holes (slots a missed piece reserved and did not need) are skipped
     uint32_t left = di.n_slots, nn = di.n_first;
-    uint64_t c = di.src / TKF_STRIDE;
-    const uint32_t* src = a.tmp + di.src;
+    uint64_t c = di.src >> 32;
+    const uint32_t* src = a.tmp + c * TKF_STRIDE + (uint32_t)di.src;
     while (left) {
         for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
             const uint32_t k = k0 + (uint32_t)lane;
@@ -308,11 +309,15 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
                 const uint32_t nf = tkf_rl(mine.n_first, j & 63);
                 if (!(nf & 0x80000000u)) {                // wave-uniform
                     const uint32_t ns = tkf_rl(mine.n_slots, j & 63);
-                    const uint64_t src = ((uint64_t)tkf_rl(src_hi, j & 63) << 32) | tkf_rl(src_lo, j & 63);
-                    const uint64_t src2 = (src / TKF_STRIDE + 1) * TKF_STRIDE;   // slot 0 of the next chunk
+                    // (chunk, slot) -> the chunk's row of tmp (a scalar base) + a 32-bit slot offset per lane; slots past
+                    // the document's n_first continue at slot 0 of the next row
+                    const uint32_t* rowp = a.tmp + (uint64_t)tkf_rl(src_hi, j & 63) * TKF_STRIDE;
+                    const uint32_t slot = tkf_rl(src_lo, j & 63);
                     const uint32_t q0 = (uint32_t)lane, q1 = 64u + (uint32_t)lane;
-                    if (q0 < ns) v0[g] = q0 < nf ? a.tmp[src + q0] : a.tmp[src2 + (q0 - nf)];
-                    if (q1 < ns) v1[g] = q1 < nf ? a.tmp[src + q1] : a.tmp[src2 + (q1 - nf)];
+                    const uint32_t o0 = q0 < nf ? slot + q0 : (uint32_t)TKF_STRIDE + (q0 - nf);
+                    const uint32_t o1 = q1 < nf ? slot + q1 : (uint32_t)TKF_STRIDE + (q1 - nf);
+                    if (q0 < ns) v0[g] = rowp[o0];
+                    if (q1 < ns) v1[g] = rowp[o1];
                 }
             }
 #pragma unroll
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
                 const uint64_t k0 = __ballot(c0 != TKF_HOLE), k1 = __ballot(c1 != TKF_HOLE);
                 const uint64_t below = (1ull << lane) - 1ull;
                 const uint32_t n0 = (uint32_t)__builtin_popcountll(k0);
-                if (c0 != TKF_HOLE) dst[__builtin_popcountll(k0 & below)] = c0;
+                if (c0 != TKF_HOLE) dst[(uint32_t)__builtin_popcountll(k0 & below)] = c0;
                 if (c1 != TKF_HOLE) dst[n0 + (uint32_t)__builtin_popcountll(k1 & below)] = c1;
                 if (a.add_eos && lane == 0) dst[n0 + (uint32_t)__builtin_popcountll(k1)] = a.eos_id;
             }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# same-box A/B of prebuilt library variants (box-to-box variance is +-3 %): tools/ab_libs.sh tools/probe/lib_A.so tools/probe/lib_B.so ...
+# runs tools/quick_merge.sh (kernel trace of the C3 and C2 shapes) once per variant, twice round-robin
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+cp tekken-rs_amd/libtekken_hip.so gpurun_out/lib_keep.so
+for rep in 1 2; do
+  for v in "$@"; do
+    cp $v tekken-rs_amd/libtekken_hip.so
+    echo "== $v (rep $rep)"
+    bash tools/quick_merge.sh | grep "^c2" || exit 1
+  done
+done
+cp gpurun_out/lib_keep.so tekken-rs_amd/libtekken_hip.so

@@ -482,3 +482,32 @@ def test_json_pattern_opt_in(tk, test_vocab, bench_vocab):
         t.set_honour_pattern(True)
     assert ei.value.kind == "InvalidConfig"
     t.close()
+
+
+@pytest.mark.gpu
+def test_merge_kernels_every_piece_length(tk, eng_small, eng_bench, test_vocab, bench_vocab):
+    """The merge kernels (csrc/tk_flat_impl.h tk_merge_lds<8|16|32>, the one-lane-per-byte loop for 33..64 bytes, pass 2
+    beyond): words of every length 2..80 that miss the vocabulary -- random letters, runs of one letter, UTF-8 words --
+    many per document, so that a wave's 64 queued pieces span several documents (the hole counts of a run of lanes
+    are combined into one atomic) and the 16-byte id stores meet every alignment and every tail length."""
+    import random
+    rng = random.Random(4242)
+    letters = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    docs = []
+    for rep in range(6):
+        words = []
+        for n in range(2, 81):
+            words.append("".join(rng.choice(letters) for _ in range(n)))
+            words.append(rng.choice(letters) * n)
+            words.append("".join(rng.choice("éü中文Ж") for _ in range(max(1, n // 3))))
+        rng.shuffle(words)
+        # short documents (a few words each: document boundaries inside one wave's items) and one long one
+        for k in range(0, len(words), 5):
+            docs.append((" ".join(words[k:k + 5])).encode())
+        docs.append((" ".join(words)).encode())
+    docs += [b"", b"zq", b"Zq" * 33, ("中" * 11).encode()]
+    data, offs = tk.pack_docs(docs)
+    for eng, v in ((eng_small, test_vocab), (eng_bench, bench_vocab)):
+        orc = helpers.oracle_for(v)
+        for bos, eos in ((True, True), (False, False)):
+            check_batch(eng, orc, data, offs, bos, eos)

@@ -282,7 +282,9 @@ __device__ __forceinline__ uint32_t tkf_rl(uint32_t v, int j) { return (uint32_t
 // load each (lane = document).  The documents are then copied EIGHT at a time: the 16 loads of a group (slots 0..63
 // and 64..127 of each document, across its chunk boundary) are issued back to back, so eight documents' worth of
 // HBM latency overlap; then each is squeezed (holes out) and stored with all 64 lanes.
+#ifndef TKA_GROUP
 #define TKA_GROUP 8
+#endif
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssembleArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);

@@ -80,6 +80,17 @@ int tk_encode_batch(tk_ctx* ctx, const uint8_t* bytes, const uint64_t* doc_offse
                     int add_bos, int add_eos, int validate_utf8, tk_result* out);
 void tk_free_result(tk_result* r);
 
+/* `Tekkenizer::encode(text, add_bos, add_eos)` for ONE document with a caller-owned output -- the reference's own call shape
+ * (src/tekkenizer.rs:378-405: one &str in, one Vec<u32> out).  No allocation; a text of up to 64 KiB is ONE kernel launch
+ * (a single workgroup splits, looks up, merges, and packs; the kernel reads the text from, and writes the ids to, mapped
+ * pinned host memory), longer ones take the batch pipeline.  ids_capacity >= len + 2 always suffices;
+ * TK_ERR_INVALID_ARG if the ids do not fit (*n_ids then holds the count needed).  Batches of up to 1024 documents / 64 KiB
+ * handed to tk_encode_batch take the same one-launch path. */
+int tk_encode_one(tk_ctx* ctx, const uint8_t* text, uint64_t len, int add_bos, int add_eos, uint32_t* ids_out,
+                  uint64_t ids_capacity, uint64_t* n_ids);
+/* Calls on this context served by the one-launch path so far (diagnostics / tests). */
+uint64_t tk_small_path_calls(const tk_ctx* ctx);
+
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference
  * tests/test_small_vocab.rs:62 -- instead of the pattern the reference hard-codes and always uses
@@ -150,6 +161,29 @@ uint64_t tk_ids18_bytes(uint64_t n_ids);
 int tk_pack_ids18_device(tk_ctx* ctx, const void* d_ids, uint64_t n_ids, void* d_packed, void* hip_stream);
 int tk_unpack_ids18_device(tk_ctx* ctx, const void* d_packed, uint64_t n_ids, void* d_ids, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Node level: every GPU of one node behind ONE call (no reference equivalent: the reference is one thread on a CPU;
+ * BASELINE north_star "shards ... across the 8xMI355X node with a single RCCL gather of token-id buffers over xGMI";
+ * SURVEY section 8b `ctx_create(.., device_ids[], n_devices, ..)`).  One process; per device one context (tables
+ * replicated), one stream, one host thread per call.  tk_node_encode_batch cuts the batch into contiguous runs of WHOLE
+ * documents with balanced bytes, every device tokenizes its run, and the id buffers are gathered on device_ids[0] with
+ * direct peer -> root RCCL transfers inside one ncclGroupStart / ncclGroupEnd (18 bits per id on the wire when every id
+ * fits) -- for every document exactly what Tekkenizer::encode returns (src/tekkenizer.rs:378-405), in document order.
+ * device_ids must be distinct (TK_ERR_INVALID_ARG otherwise).  RCCL is opened with dlopen only when n_devices > 1.
+ * The result is released with tk_free_result. */
+typedef struct tk_node tk_node;
+int tk_node_create(const uint8_t* token_bytes, const uint32_t* token_offsets, uint32_t n_ranks, uint32_t num_special_tokens,
+                   uint32_t bos_id, uint32_t eos_id, const int* device_ids, int n_devices, tk_node** out_node);
+void tk_node_destroy(tk_node* node);
+/* node == NULL: the last failing tk_node_create on this thread */
+const char* tk_node_last_error(const tk_node* node);
+int tk_node_encode_batch(tk_node* node, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
+                         int add_eos, tk_result* out);
+int tk_node_n_devices(const tk_node* node);
+/* Device timings of the last tk_node_encode_batch: the slowest device's tokenization pipeline, and the exchange on the root
+ * (first receive posted .. offsets rebased), milliseconds. */
+int tk_node_last_timing(const tk_node* node, float* kernels_ms_max, float* gather_ms);
+
 /* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
 int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);
@@ -210,6 +244,10 @@ int tk_tokenizer_is_special(const tk_tokenizer* t, uint32_t id);
 int tk_tokenizer_is_byte(const tk_tokenizer* t, uint32_t id);
 int tk_tokenizer_id_to_piece(tk_tokenizer* t, uint32_t id, char** text, size_t* len);
 int tk_tokenizer_id_to_byte_piece(tk_tokenizer* t, uint32_t id, int policy, uint8_t** bytes, size_t* len);
+/* config.pattern of the loaded tekken.json (src/config.rs:38-49; the reference parses and ignores it, src/tekkenizer.rs:74),
+ * and whether the object came from a TK_TABLE_CACHE_DIR side file (row f-2) rather than from parsing the JSON. */
+const char* tk_tokenizer_json_pattern(const tk_tokenizer* t);
+int tk_tokenizer_from_cache(const tk_tokenizer* t);
 /* The engine context behind the tokenizer (NULL for host-only objects). */
 tk_ctx* tk_tokenizer_ctx(tk_tokenizer* t);
 /* The validated rank table (for building an oracle beside it in tests). */

@@ -57,6 +57,10 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
                                 uint64_t n_docs, int add_bos, int add_eos, uint32_t* out_ids,
                                 uint64_t* out_offs, int n_threads);
 
+/* Wall time (seconds) spent inside the last tk_oracle_encode_batch call of this process: what bench.py reports as the
+ * CPU baseline (1 thread) and as cpu_baseline_nt (n_threads > 1). */
+double tk_oracle_last_batch_seconds(void);
+
 /* 2-bit class of a code point: 0=O 1=L 2=N 3=S (tables generated from Python `regex`). */
 int tk_oracle_class(uint32_t cp);
 

@@ -15,10 +15,11 @@ _LIB = None
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libtk_oracle.so")
+    name = "libtk_oracle_asan.so" if os.environ.get("TK_TEST_SANITIZE") else "libtk_oracle.so"   # tests/test_sanitizers.py
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "tk_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libtk_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
     return so
 
 
@@ -47,6 +48,7 @@ def lib():
         L.tk_oracle_class2.argtypes = [ctypes.c_uint32]
         L.tk_oracle_class.restype = ctypes.c_int
         L.tk_oracle_class.argtypes = [ctypes.c_uint32]
+        L.tk_oracle_last_batch_seconds.restype = ctypes.c_double
         L.tk_oracle_fnv1a.restype = ctypes.c_uint64
         L.tk_oracle_fnv1a.argtypes = [u32p, ctypes.c_uint64]
         _LIB = L
@@ -125,6 +127,11 @@ class Oracle:
                                          int(add_bos), int(add_eos), _p(out, ctypes.c_uint32),
                                          _p(oo, ctypes.c_uint64), threads)
         return out[:t].copy(), oo
+
+
+def last_batch_seconds() -> float:
+    """Wall time spent inside the last Oracle.encode_batch call (the C loop alone, without this binding's buffers)."""
+    return float(lib().tk_oracle_last_batch_seconds())
 
 
 def fnv1a(ids: np.ndarray) -> int:

@@ -104,6 +104,10 @@ def lib():
     L.tk_encode_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(_Result)]
     L.tk_free_result.argtypes = [ctypes.POINTER(_Result)]
+    L.tk_encode_one.restype = ctypes.c_int
+    L.tk_encode_one.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, ctypes.c_uint64, u64p]
+    L.tk_small_path_calls.restype = ctypes.c_uint64
+    L.tk_small_path_calls.argtypes = [vp]
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
@@ -177,6 +181,22 @@ def lib():
                                                 ctypes.POINTER(ctypes.c_size_t)]
     L.tk_tokenizer_ctx.restype = vp
     L.tk_tokenizer_ctx.argtypes = [vp]
+    L.tk_node_create.restype = ctypes.c_int
+    L.tk_node_create.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
+    L.tk_node_destroy.argtypes = [vp]
+    L.tk_node_last_error.restype = ctypes.c_char_p
+    L.tk_node_last_error.argtypes = [vp]
+    L.tk_node_encode_batch.restype = ctypes.c_int
+    L.tk_node_encode_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Result)]
+    L.tk_node_n_devices.restype = ctypes.c_int
+    L.tk_node_n_devices.argtypes = [vp]
+    L.tk_node_last_timing.restype = ctypes.c_int
+    L.tk_node_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.tk_tokenizer_json_pattern.restype = ctypes.c_char_p
+    L.tk_tokenizer_json_pattern.argtypes = [vp]
+    L.tk_tokenizer_from_cache.restype = ctypes.c_int
+    L.tk_tokenizer_from_cache.argtypes = [vp]
     L.tk_tokenizer_rank_table.restype = ctypes.c_int
     L.tk_tokenizer_rank_table.argtypes = [vp, ctypes.POINTER(u8p), ctypes.POINTER(u32p), u32p]
     _LIB = L
@@ -279,6 +299,21 @@ class Engine:
         if rc != TK_OK:
             raise self._err(rc)
         return ids_out[:int(n.value)], offsets_out
+
+    def encode_one(self, text, add_bos=False, add_eos=False, out=None):
+        """tk_encode_one: one document, caller-owned output (numpy uint32 array of >= len + 2 entries; made if None)."""
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        if out is None:
+            out = np.empty(len(raw) + 2, np.uint32)
+        n = ctypes.c_uint64(0)
+        rc = lib().tk_encode_one(self._h, raw, len(raw), int(add_bos), int(add_eos), _p(out, ctypes.c_uint32), len(out), ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        return out[:n.value]
+
+    def small_path_calls(self):
+        """Calls served by the one-launch small-batch path so far."""
+        return int(lib().tk_small_path_calls(self._h))
 
     def encode_docs(self, docs, add_bos=True, add_eos=True, validate_utf8=False):
         data, offs = pack_docs(docs)
@@ -394,6 +429,54 @@ class Engine:
             a, b = int(offs[d]), int(offs[d + 1])
             res.append(np.nonzero(out[a:b])[0].tolist())
         return res
+
+
+class Node:
+    """tk_node_*: every listed GPU behind one call -- documents sharded whole by bytes, one RCCL gather of the id buffers to
+    devices[0] (include/tekken_hip.h, csrc/tk_node.cpp).  One process; the path a Rust / C host calls."""
+
+    def __init__(self, token_bytes, num_special, bos_id, eos_id, devices=(0,)):
+        toks = list(token_bytes)
+        offs = np.zeros(len(toks) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(t) for t in toks], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(toks) or b"\0", dtype=np.uint8)
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = lib().tk_node_create(_p(blob, ctypes.c_uint8), _p(offs, ctypes.c_uint32), len(toks), num_special, bos_id, eos_id,
+                                  devs, len(devices), ctypes.byref(h))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_node_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tk_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def n_devices(self):
+        return lib().tk_node_n_devices(self._h)
+
+    def encode_batch(self, data, offs, add_bos=True, add_eos=True):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        res = _Result()
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        rc = lib().tk_node_encode_batch(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1, int(add_bos),
+                                        int(add_eos), ctypes.byref(res))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_node_last_error(self._h).decode())
+        return _take_result(res)
+
+    def last_timing(self):
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        lib().tk_node_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
+        return {"kernels_ms_max": a.value, "gather_ms": b.value}
 
 
 class _Pinned:
@@ -562,6 +645,14 @@ class Tekkenizer:
 
     def is_byte(self, token_id):
         return bool(lib().tk_tokenizer_is_byte(self._h, token_id))
+
+    def json_pattern(self):
+        """config.pattern of the loaded tekken.json (parsed and ignored by the reference, src/tekkenizer.rs:74)."""
+        return lib().tk_tokenizer_json_pattern(self._h).decode("utf-8")
+
+    def from_cache(self):
+        """True when the object was loaded from a TK_TABLE_CACHE_DIR side file instead of the JSON (row f-2)."""
+        return bool(lib().tk_tokenizer_from_cache(self._h))
 
     def engine(self):
         """The engine context behind this tokenizer (None for host-only objects)."""

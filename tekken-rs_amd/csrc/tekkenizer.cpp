@@ -580,7 +580,7 @@ Tekkenizer* Tekkenizer::from_json(const char* json, size_t len, int device_id, T
 // key is 128 bits over length + content, the file carries magic, version, key, sizes and a tail marker, and anything
 // that does not check out falls back to the JSON.
 #define TK_MODEL_MAGIC 0x4D4B5454u /* "TTKM" */
-#define TK_MODEL_VERSION 1u
+#define TK_MODEL_VERSION 3u   /* 2: config.pattern is kept (set_honour_pattern after a cached load); 3: payload checksum */
 
 static void content_key(const std::string& c, uint64_t key[2]) {
     uint64_t a = 0xCBF29CE484222325ull ^ c.size(), b = 0x9E3779B97F4A7C15ull + c.size();
@@ -608,6 +608,7 @@ struct ModelHead {
     uint64_t key[2];
     uint64_t vocab_size, num_special_tokens, n_special, n_ranks, blob_bytes, strings_bytes;
     uint32_t has_audio, version_len;
+    uint32_t pattern_len, pad;
 };
 }  // namespace
 
@@ -626,16 +627,24 @@ bool Tekkenizer::save_model_cache(const std::string& path, const uint64_t key[2]
         strings.append((const char*)&l, 4);
         strings += s.token_str;
     }
+    strings += pattern_;                     // config.pattern, last (the reference ignores it; the opt-in of row f-3 needs it)
     ModelHead h;
     memset(&h, 0, sizeof(h));
     h.magic = TK_MODEL_MAGIC; h.version = TK_MODEL_VERSION; h.key[0] = key[0]; h.key[1] = key[1];
     h.vocab_size = vocab_size_; h.num_special_tokens = num_special_tokens_; h.n_special = special_tokens_.size();
     h.n_ranks = offs_.size() - 1; h.blob_bytes = offs_.back(); h.strings_bytes = strings.size();
     h.has_audio = has_audio_ ? 1 : 0; h.version_len = (uint32_t)version_.size();
+    h.pattern_len = (uint32_t)pattern_.size();
     const uint32_t tail = TK_MODEL_MAGIC;
+    // the payload checksum goes in front of the tail marker: a flipped bit anywhere makes the file "not check out"
+    uint64_t sum = tk_sum64(key[0] ^ key[1], &h, sizeof(h));
+    sum = tk_sum64(sum, offs_.data(), 4 * offs_.size());
+    sum = tk_sum64(sum, blob_.data(), h.blob_bytes);
+    sum = tk_sum64(sum, strings.data(), strings.size());
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(offs_.data(), 4, offs_.size(), f) == offs_.size() &&
               (h.blob_bytes == 0 || fwrite(blob_.data(), 1, h.blob_bytes, f) == h.blob_bytes) &&
-              (strings.empty() || fwrite(strings.data(), 1, strings.size(), f) == strings.size()) && fwrite(&tail, 4, 1, f) == 1;
+              (strings.empty() || fwrite(strings.data(), 1, strings.size(), f) == strings.size()) && fwrite(&sum, 8, 1, f) == 1 &&
+              fwrite(&tail, 4, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
     if (!ok) remove(tmp.c_str());
@@ -650,16 +659,25 @@ Tekkenizer* Tekkenizer::load_model_cache(const std::string& path, const uint64_t
     std::vector<uint8_t> blob;
     std::string strings;
     uint32_t tail = 0;
+    uint64_t want = 0;
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && h.magic == TK_MODEL_MAGIC && h.version == TK_MODEL_VERSION && h.key[0] == key[0] &&
               h.key[1] == key[1] && h.n_ranks < (1ull << 31) && h.blob_bytes < (1ull << 32) && h.strings_bytes < (1ull << 31) &&
-              h.n_special <= h.num_special_tokens && h.n_special < (1ull << 24) && h.version_len <= h.strings_bytes;
+              h.n_special <= h.num_special_tokens && h.n_special < (1ull << 24) && h.version_len <= h.strings_bytes &&
+              (uint64_t)h.version_len + h.pattern_len <= h.strings_bytes;
     if (ok) {
         offs.resize(h.n_ranks + 1);
         blob.resize(h.blob_bytes);
         strings.resize(h.strings_bytes);
         ok = fread(offs.data(), 4, offs.size(), f) == offs.size() && (blob.empty() || fread(blob.data(), 1, blob.size(), f) == blob.size()) &&
-             (strings.empty() || fread(&strings[0], 1, strings.size(), f) == strings.size()) && fread(&tail, 4, 1, f) == 1 &&
-             tail == TK_MODEL_MAGIC && offs[0] == 0 && offs.back() == h.blob_bytes;
+             (strings.empty() || fread(&strings[0], 1, strings.size(), f) == strings.size()) && fread(&want, 8, 1, f) == 1 &&
+             fread(&tail, 4, 1, f) == 1 && tail == TK_MODEL_MAGIC && offs[0] == 0 && offs.back() == h.blob_bytes;
+        if (ok) {
+            uint64_t sum = tk_sum64(key[0] ^ key[1], &h, sizeof(h));
+            sum = tk_sum64(sum, offs.data(), 4 * offs.size());
+            sum = tk_sum64(sum, blob.data(), blob.size());
+            sum = tk_sum64(sum, strings.data(), strings.size());
+            ok = sum == want;
+        }
     }
     fclose(f);
     for (size_t r = 0; ok && r < h.n_ranks; ++r) ok = offs[r + 1] >= offs[r];
@@ -676,9 +694,12 @@ Tekkenizer* Tekkenizer::load_model_cache(const std::string& path, const uint64_t
         all.push_back(SpecialTokenInfo{r, strings.substr(q, l), ic != 0});
         q += l;
     }
-    if (q != strings.size() || all.size() != h.num_special_tokens) return nullptr;
-    return assemble(std::move(all), std::move(blob), std::move(offs), h.vocab_size, h.num_special_tokens, version, h.has_audio != 0,
-                    device_id, err);
+    if (q + h.pattern_len != strings.size() || all.size() != h.num_special_tokens) return nullptr;
+    const std::string pattern = strings.substr(q, h.pattern_len);
+    Tekkenizer* t = assemble(std::move(all), std::move(blob), std::move(offs), h.vocab_size, h.num_special_tokens, version, h.has_audio != 0,
+                             device_id, err);
+    if (t) { t->pattern_ = pattern; t->from_cache_ = true; }
+    return t;
 }
 
 Tekkenizer* Tekkenizer::from_file(const std::string& path, int device_id, TokenizerError& err) {
@@ -750,12 +771,16 @@ TokenizerError Tekkenizer::encode_batch(const uint8_t* bytes, const uint64_t* do
 }
 
 TokenizerError Tekkenizer::encode(const char* text, size_t len, bool add_bos, bool add_eos, std::vector<uint32_t>& out) {
-    uint64_t offs[2] = {0, len};
-    tk_result r;
-    TokenizerError e = encode_batch((const uint8_t*)text, offs, 1, add_bos, add_eos, &r);
-    if (!e.ok()) return e;
-    out.assign(r.ids, r.ids + r.n_ids);
-    tk_free_result(&r);
+    uint32_t id;
+    if (add_bos) { TokenizerError e = bos_id(id); if (!e.ok()) return e; }  // :394-397
+    if (add_eos) { TokenizerError e = eos_id(id); if (!e.ok()) return e; }  // :399-402
+    if (!ctx_) return mk(TK_ERR_NO_DEVICE, "tokenizer was created without a device (host-only object)");
+    // one document, caller-owned output: no allocation, one launch for texts of up to 64 KiB (tk_encode_one)
+    out.resize(len + 2);
+    uint64_t n = 0;
+    const int rc = tk_encode_one(ctx_, (const uint8_t*)text, len, add_bos, add_eos, out.data(), out.size(), &n);
+    if (rc != TK_OK) { out.clear(); return mk(rc, tk_last_error(ctx_)); }
+    out.resize(n);
     return TokenizerError();
 }
 
@@ -974,6 +999,8 @@ extern "C" int tk_tokenizer_id_to_byte_piece(tk_tokenizer* h, uint32_t id, int p
 }
 
 extern "C" tk_ctx* tk_tokenizer_ctx(tk_tokenizer* h) { return h ? h->t->ctx() : nullptr; }
+extern "C" const char* tk_tokenizer_json_pattern(const tk_tokenizer* h) { return h ? h->t->json_pattern().c_str() : ""; }
+extern "C" int tk_tokenizer_from_cache(const tk_tokenizer* h) { return h && h->t->from_cache(); }
 
 extern "C" int tk_tokenizer_rank_table(const tk_tokenizer* h, const uint8_t** blob, const uint32_t** offsets,
                                        uint32_t* n_ranks) {

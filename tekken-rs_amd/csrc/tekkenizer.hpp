@@ -99,6 +99,7 @@ public:
     // to the matcher; any other string is refused.  honour = false restores the reference's behaviour (pattern ignored).
     TokenizerError set_honour_pattern(bool honour);
     const std::string& json_pattern() const { return pattern_; }
+    bool from_cache() const { return from_cache_; }              // loaded from a TK_TABLE_CACHE_DIR side file (row f-2)
     const std::vector<uint8_t>& rank_blob() const { return blob_; }
     const std::vector<uint32_t>& rank_offsets() const { return offs_; }
     std::string last_error;
@@ -125,6 +126,7 @@ private:
     std::vector<uint32_t> offs_;
     bool has_audio_ = false;
     std::string pattern_;                                        // config.pattern as loaded (ignored unless opted in)
+    bool from_cache_ = false;
 };
 
 // helpers exposed for tests

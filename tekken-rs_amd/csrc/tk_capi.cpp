@@ -12,6 +12,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tekken_hip.h"
@@ -44,7 +45,64 @@ struct DevBuf {
     }
 };
 
+// Pinned result buffers of tk_encode_batch / tk_decode_batch: a process-wide pool.  hipHostMalloc / hipHostFree cost
+// hundreds of microseconds each (they map the pages into every device); a caller that encodes batch after batch gets the
+// same blocks back from tk_free_result instead.  Bounded: at most 8 free blocks / 1 GiB are kept.
+struct PinPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;            // handed out
+    std::vector<std::pair<void*, size_t>> free_blocks;
+    size_t free_bytes = 0;
+    void* get(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].second >= bytes && free_blocks[i].second <= 4 * bytes + (1u << 16) &&
+                    (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
+                    best = i;
+            if (best != free_blocks.size()) {
+                std::pair<void*, size_t> b = free_blocks[best];
+                free_blocks.erase(free_blocks.begin() + (long)best);
+                free_bytes -= b.second;
+                live[b.first] = b.second;
+                return b.first;
+            }
+        }
+        const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 8;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> lock(mu);
+        live[p] = want;
+        return p;
+    }
+    void put(void* p) {
+        if (!p) return;
+        size_t sz = 0;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = live.find(p);
+            if (it == live.end()) { sz = 0; }
+            else {
+                sz = it->second;
+                live.erase(it);
+                if (free_blocks.size() < 8 && free_bytes + sz <= (1ull << 30)) {
+                    free_blocks.push_back({p, sz});
+                    free_bytes += sz;
+                    return;
+                }
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinPool g_pin_pool;
+
 }  // namespace
+
+void* tk_pinned_get(size_t bytes) { return g_pin_pool.get(bytes); }
+void tk_pinned_put(void* p) { g_pin_pool.put(p); }
 
 struct tk_ctx {
     int device = 0;
@@ -73,7 +131,18 @@ struct tk_ctx {
     DevBuf in_bytes2, in_offs2, out_ids2, out_offs2;
     uint64_t* h_offs_stage[2] = {nullptr, nullptr};   // pinned: slice-relative document offsets going up
     uint64_t h_offs_cap = 0;
+    // small batches in one launch (tk_small_kernel): mapped pinned host buffers the kernel reads / writes directly
+    uint8_t* hs_in = nullptr;      // [TK_SMALL_MAX_BYTES] text | [TK_SMALL_MAX_DOCS + 1] u64 offsets
+    uint32_t* hs_out = nullptr;    // [TK_SMALL_MAX_BYTES + 2 * TK_SMALL_MAX_DOCS] ids | [TK_SMALL_MAX_DOCS + 1] u64 offsets | [4] status
+    void* ds_in = nullptr;         // the same buffers as the device sees them
+    void* ds_out = nullptr;
+    DevBuf s_offs;
+    uint64_t n_small_calls = 0;    // calls served by the one-launch path (tk_last_stats_ex)
 };
+
+#define TK_SMALL_IDS_CAP (TK_SMALL_MAX_BYTES + 2 * TK_SMALL_MAX_DOCS)
+#define TK_SMALL_OUT_OFFS_WORD (TK_SMALL_IDS_CAP)                          /* u32 index of the u64 offsets in hs_out (8-byte aligned) */
+#define TK_SMALL_STATUS_WORD (TK_SMALL_OUT_OFFS_WORD + 2 * (TK_SMALL_MAX_DOCS + 1) + 2)
 
 #define TK_HIP(ctx, call)                                                                          \
     do {                                                                                           \
@@ -202,6 +271,9 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     }
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    if (c->hs_in) (void)hipHostFree(c->hs_in);
+    if (c->hs_out) (void)hipHostFree(c->hs_out);
+    c->s_offs.release();
     delete c;
 }
 
@@ -551,6 +623,105 @@ static int stage_input(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offs
     return TK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// small batches in ONE launch (tk_small_kernel).  The reference's own signature is one &str per call
+// (src/tekkenizer.rs:378-405): through the batch pipeline that is about ten launches, two copies and a host sync.
+// ------------------------------------------------------------------------------------------
+static bool small_eligible(const tk_ctx* c, uint64_t n_docs, uint64_t n_bytes) {
+    static const bool off = getenv("TK_NO_SMALL_PATH") != nullptr;
+    return !off && c->pattern == 0 && c->pipeline_forced == 0 && n_docs >= 1 && n_docs <= TK_SMALL_MAX_DOCS && n_bytes <= TK_SMALL_MAX_BYTES;
+}
+
+static int small_prepare(tk_ctx* c) {
+    if (c->hs_in) return TK_OK;
+    const size_t in_bytes = TK_SMALL_MAX_BYTES + (TK_SMALL_MAX_DOCS + 1) * 8;
+    const size_t out_bytes = (size_t)(TK_SMALL_STATUS_WORD + 4) * 4;
+    TK_HIP(c, hipHostMalloc((void**)&c->hs_in, in_bytes, hipHostMallocMapped));
+    TK_HIP(c, hipHostMalloc((void**)&c->hs_out, out_bytes, hipHostMallocMapped));
+    TK_HIP(c, hipHostGetDevicePointer(&c->ds_in, c->hs_in, 0));
+    TK_HIP(c, hipHostGetDevicePointer(&c->ds_out, c->hs_out, 0));
+    TK_HIP(c, c->staging.reserve((size_t)(TK_SMALL_IDS_CAP + 64) * 4));
+    TK_HIP(c, c->counts.reserve((TK_SMALL_MAX_DOCS + 1) * 4));
+    TK_HIP(c, c->in_bytes.reserve(TK_SMALL_MAX_BYTES + 64));
+    TK_HIP(c, c->s_offs.reserve((TK_SMALL_MAX_DOCS + 1) * 8));
+    return TK_OK;
+}
+
+// hs_in holds the text and (behind it) the document offsets.  *fallback = true: a document needs pass 2 (a piece that
+// does not fit a window) -- nothing was produced, the caller takes the batch pipeline.  Otherwise the ids are in
+// hs_out[0 .. *n_ids) and the id offsets at hs_out + TK_SMALL_OUT_OFFS_WORD when this returns.
+static int run_small(tk_ctx* c, uint64_t n_docs, uint64_t n_bytes, int add_bos, int add_eos, uint64_t* n_ids, bool* fallback) {
+    uint64_t* h_offs = (uint64_t*)(c->hs_in + TK_SMALL_MAX_BYTES);
+    volatile uint32_t* status = (volatile uint32_t*)(c->hs_out + TK_SMALL_STATUS_WORD);
+    TkEncodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_docs = n_docs;
+    // A few short strings are read by the kernel straight from pinned host memory (one PCIe round trip per window); beyond
+    // that the copy engine is the better reader.
+    if (n_bytes <= 4096 && n_docs <= 16) {
+        a.bytes = (const uint8_t*)c->ds_in;
+        a.doc_offs = (const uint64_t*)((const uint8_t*)c->ds_in + TK_SMALL_MAX_BYTES);
+    } else {
+        if (n_bytes) TK_HIP(c, hipMemcpyAsync(c->in_bytes.p, c->hs_in, n_bytes, hipMemcpyHostToDevice, c->stream));
+        TK_HIP(c, hipMemcpyAsync(c->s_offs.p, h_offs, (n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        a.bytes = (const uint8_t*)c->in_bytes.p;
+        a.doc_offs = (const uint64_t*)c->s_offs.p;
+    }
+    a.staging = (uint32_t*)c->staging.p;
+    a.counts = (uint32_t*)c->counts.p;
+    a.add_bos = add_bos;
+    a.add_eos = add_eos;
+    a.t = c->dview;
+    status[0] = 0xFFFFFFFFu;
+    uint32_t* d_out = (uint32_t*)c->ds_out;
+    TK_HIP(c, tk_launch_small(a, d_out, (uint64_t*)(d_out + TK_SMALL_OUT_OFFS_WORD), d_out + TK_SMALL_STATUS_WORD, c->stream));
+    TK_HIP(c, hipStreamSynchronize(c->stream));
+    if (status[0] == 0xFFFFFFFFu) { c->err = "the small-batch kernel did not report"; return TK_ERR_RUNTIME; }
+    *fallback = status[0] != 0u;
+    *n_ids = status[1];
+    if (!*fallback) {
+        c->n_small_calls++;
+        c->n_flagged = 0; c->n_long_docs = 0; c->pipeline_ms = 0.f; c->encode_ms = 0.f;
+    }
+    return TK_OK;
+}
+
+/* Tekkenizer::encode for ONE &str with a caller-owned output (the reference's own call shape): no allocation, and for
+ * texts of up to 64 KiB one kernel launch.  ids_capacity >= len + 2 always suffices. */
+extern "C" int tk_encode_one(tk_ctx* c, const uint8_t* text, uint64_t len, int add_bos, int add_eos, uint32_t* ids_out,
+                             uint64_t ids_capacity, uint64_t* n_ids_out) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if ((!text && len) || !n_ids_out || (!ids_out && ids_capacity)) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    *n_ids_out = 0;
+    TK_HIP(c, hipSetDevice(c->device));
+    uint64_t n_ids = 0;
+    if (small_eligible(c, 1, len)) {
+        int rc = small_prepare(c);
+        if (rc != TK_OK) return rc;
+        if (len) memcpy(c->hs_in, text, len);
+        uint64_t* h_offs = (uint64_t*)(c->hs_in + TK_SMALL_MAX_BYTES);
+        h_offs[0] = 0; h_offs[1] = len;
+        bool fallback = false;
+        if ((rc = run_small(c, 1, len, add_bos, add_eos, &n_ids, &fallback)) != TK_OK) return rc;
+        if (!fallback) {
+            *n_ids_out = n_ids;
+            if (n_ids > ids_capacity) { c->err = "ids_out is too small"; return TK_ERR_INVALID_ARG; }
+            if (n_ids) memcpy(ids_out, c->hs_out, n_ids * 4);
+            return TK_OK;
+        }
+    }
+    const uint64_t offs[2] = {0, len};
+    int rc = stage_input(c, text, offs, 1);
+    if (rc != TK_OK) return rc;
+    rc = run_pipeline(c, (const uint8_t*)c->in_bytes.p, (const uint64_t*)c->in_offs.p, 1, len, add_bos, add_eos, c->stream, &n_ids);
+    if (rc != TK_OK) return rc;
+    *n_ids_out = n_ids;
+    if (n_ids > ids_capacity) { c->err = "ids_out is too small"; return TK_ERR_INVALID_ARG; }
+    if (n_ids) TK_HIP(c, hipMemcpy(ids_out, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost));
+    return TK_OK;
+}
+
 extern "C" int tk_encode_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs,
                                int add_bos, int add_eos, int validate_utf8, tk_result* out) {
     if (!c) return TK_ERR_INVALID_ARG;
@@ -562,6 +733,30 @@ extern "C" int tk_encode_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* 
     if (rc != TK_OK) return rc;
     TK_HIP(c, hipSetDevice(c->device));
     const uint64_t n_bytes = doc_offsets[n_docs];
+    if (small_eligible(c, n_docs, n_bytes)) {
+        // one launch for the whole batch; UTF-8 is validated on the host (same RFC 3629 rules as tk_validate_kernel)
+        if (validate_utf8) {
+            uint64_t bad = 0;
+            for (uint64_t d = 0; d < n_docs; ++d)
+                if (!tekken::utf8_valid(bytes + doc_offsets[d], doc_offsets[d + 1] - doc_offsets[d])) ++bad;
+            if (bad) { c->err = std::to_string(bad) + " document(s) are not valid UTF-8"; return TK_ERR_INVALID_UTF8; }
+        }
+        if ((rc = small_prepare(c)) != TK_OK) return rc;
+        if (n_bytes) memcpy(c->hs_in, bytes, n_bytes);
+        memcpy(c->hs_in + TK_SMALL_MAX_BYTES, doc_offsets, (n_docs + 1) * 8);
+        uint64_t n_ids = 0;
+        bool fallback = false;
+        if ((rc = run_small(c, n_docs, n_bytes, add_bos, add_eos, &n_ids, &fallback)) != TK_OK) return rc;
+        if (!fallback) {
+            uint32_t* h_ids = (uint32_t*)tk_pinned_get((n_ids ? n_ids : 1) * 4);
+            uint64_t* h_offs = (uint64_t*)tk_pinned_get((n_docs + 1) * 8);
+            if (!h_ids || !h_offs) { tk_pinned_put(h_ids); tk_pinned_put(h_offs); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+            if (n_ids) memcpy(h_ids, c->hs_out, n_ids * 4);
+            memcpy(h_offs, c->hs_out + TK_SMALL_OUT_OFFS_WORD, (n_docs + 1) * 8);
+            out->ids = h_ids; out->offsets = h_offs; out->n_ids = n_ids; out->n_docs = n_docs;
+            return TK_OK;
+        }
+    }
     if ((rc = stage_input(c, bytes, doc_offsets, n_docs)) != TK_OK) return rc;
     if (validate_utf8) {
         uint32_t bad = 0;
@@ -579,16 +774,16 @@ extern "C" int tk_encode_batch(tk_ctx* c, const uint8_t* bytes, const uint64_t* 
     rc = run_pipeline(c, (const uint8_t*)c->in_bytes.p, (const uint64_t*)c->in_offs.p, n_docs, n_bytes, add_bos,
                       add_eos, c->stream, &n_ids);
     if (rc != TK_OK) return rc;
-    uint32_t* h_ids = nullptr;
-    uint64_t* h_offs = nullptr;
-    TK_HIP(c, hipHostMalloc((void**)&h_ids, (n_ids ? n_ids : 1) * 4, hipHostMallocDefault));
-    hipError_t e = hipHostMalloc((void**)&h_offs, (n_docs + 1) * 8, hipHostMallocDefault);
-    if (e != hipSuccess) { (void)hipHostFree(h_ids); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    // (pinned buffers from the process-wide pool: no hipHostMalloc per call once the pool is warm)
+    uint32_t* h_ids = (uint32_t*)tk_pinned_get((n_ids ? n_ids : 1) * 4);
+    uint64_t* h_offs = (uint64_t*)tk_pinned_get((n_docs + 1) * 8);
+    if (!h_ids || !h_offs) { tk_pinned_put(h_ids); tk_pinned_put(h_offs); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    hipError_t e = hipSuccess;
     if (n_ids) e = hipMemcpyAsync(h_ids, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_offs, c->out_offs.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        (void)hipHostFree(h_ids); (void)hipHostFree(h_offs);
+        tk_pinned_put(h_ids); tk_pinned_put(h_offs);
         c->err = std::string("result copy failed: ") + hipGetErrorString(e);
         return TK_ERR_RUNTIME;
     }
@@ -684,13 +879,23 @@ extern "C" int tk_encode_batch_pipelined(tk_ctx* c, const uint8_t* bytes, const 
     uint64_t flagged = 0, longd = 0;
     // the offsets staging of slice k is rewritten by upload_slice(k + 2): that copy must have been consumed -- it has, the
     // kernels of slice k (which waited for it) are complete when run_pipeline returns
-    if ((rc = upload_slice(0)) != TK_OK) return rc;
-    for (size_t k = 0; k < n_slices; ++k) {
+    // (inside the loop a failing HIP call sets rc and leaves the loop: the drain below must run whatever happened)
+#define TK_HIP_BRK(call)                                                                           \
+    {                                                                                              \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            c->err = std::string(#call) + ": " + hipGetErrorString(_e);                            \
+            rc = TK_ERR_RUNTIME;                                                                   \
+            break;                                                                                 \
+        }                                                                                          \
+    }
+    rc = upload_slice(0);
+    for (size_t k = 0; rc == TK_OK && k < n_slices; ++k) {
         const int b = (int)(k & 1);
         if (k + 1 < n_slices && (rc = upload_slice(k + 1)) != TK_OK) break;
         const uint64_t d0 = cut[k], d1 = cut[k + 1], nb = doc_offsets[d1] - doc_offsets[d0];
-        TK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
-        if (k >= 2) TK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_out[b], 0));   // the ids of slice k - 2 have left this output set
+        TK_HIP_BRK(hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
+        if (k >= 2) TK_HIP_BRK(hipStreamWaitEvent(c->stream, c->ev_out[b], 0));   // the ids of slice k - 2 have left this output set
         uint64_t n_ids = 0;
         rc = run_pipeline(c, (const uint8_t*)inb[b]->p, (const uint64_t*)ino[b]->p, d1 - d0, nb, add_bos, add_eos, c->stream, &n_ids);
         if (rc != TK_OK) break;
@@ -703,17 +908,18 @@ extern "C" int tk_encode_batch_pipelined(tk_ctx* c, const uint8_t* bytes, const 
             break;
         }
         // device -> host on the output stream (run_pipeline returned after its stream drained: the ids are complete)
-        if (n_ids) TK_HIP(c, hipMemcpyAsync(ids_out + id_base, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost, c->s_out));
-        TK_HIP(c, hipMemcpyAsync(offsets_out + d0 + 1, (const uint64_t*)c->out_offs.p + 1, (d1 - d0) * 8, hipMemcpyDeviceToHost, c->s_out));
-        TK_HIP(c, hipEventRecord(c->ev_out[b], c->s_out));
+        if (n_ids) TK_HIP_BRK(hipMemcpyAsync(ids_out + id_base, c->out_ids.p, n_ids * 4, hipMemcpyDeviceToHost, c->s_out));
+        TK_HIP_BRK(hipMemcpyAsync(offsets_out + d0 + 1, (const uint64_t*)c->out_offs.p + 1, (d1 - d0) * 8, hipMemcpyDeviceToHost, c->s_out));
+        TK_HIP_BRK(hipEventRecord(c->ev_out[b], c->s_out));
         std::swap(c->out_ids, c->out_ids2);
         std::swap(c->out_offs, c->out_offs2);
         id_base += n_ids;
     }
+#undef TK_HIP_BRK
     // drain the copy streams whatever happened (buffers must not be in flight when the call returns)
     (void)hipStreamSynchronize(c->s_in);
     hipError_t e = hipStreamSynchronize(c->s_out);
-    if (rc != TK_OK) return rc;
+    if (rc != TK_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     if (e != hipSuccess) { c->err = std::string("result copy failed: ") + hipGetErrorString(e); return TK_ERR_RUNTIME; }
     // slice-relative id offsets -> batch offsets
     uint64_t base = 0;
@@ -758,8 +964,8 @@ extern "C" int tk_unpack_ids18_device(tk_ctx* c, const void* d_packed, uint64_t 
 
 extern "C" void tk_free_result(tk_result* r) {
     if (!r) return;
-    if (r->ids) (void)hipHostFree(r->ids);
-    if (r->offsets) (void)hipHostFree(r->offsets);
+    tk_pinned_put(r->ids);
+    tk_pinned_put(r->offsets);
     memset(r, 0, sizeof(*r));
 }
 
@@ -771,6 +977,8 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
     if (encode_kernel_ms) *encode_kernel_ms = c->encode_ms;
     return TK_OK;
 }
+
+extern "C" uint64_t tk_small_path_calls(const tk_ctx* c) { return c ? c->n_small_calls : 0; }
 
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;
@@ -978,16 +1186,15 @@ extern "C" int tk_decode_batch(tk_ctx* c, const uint32_t* ids, const uint64_t* i
     rc = run_decode(c, (const uint32_t*)c->dec_in_ids.p, (const uint64_t*)c->dec_in_offs.p, n_docs, n_ids, policy, c->stream,
                     &n_bytes, bad_doc);
     if (rc != TK_OK) return rc;
-    uint8_t* hb = nullptr;
-    uint64_t* ho = nullptr;
-    TK_HIP(c, hipHostMalloc((void**)&hb, n_bytes ? n_bytes : 1, hipHostMallocDefault));
-    hipError_t e = hipHostMalloc((void**)&ho, (n_docs + 1) * 8, hipHostMallocDefault);
-    if (e != hipSuccess) { (void)hipHostFree(hb); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    uint8_t* hb = (uint8_t*)tk_pinned_get(n_bytes ? n_bytes : 1);
+    uint64_t* ho = (uint64_t*)tk_pinned_get((n_docs + 1) * 8);
+    if (!hb || !ho) { tk_pinned_put(hb); tk_pinned_put(ho); c->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    hipError_t e = hipSuccess;
     if (n_bytes) e = hipMemcpyAsync(hb, c->dec_bytes.p, n_bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ho, c->dec_offs.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        (void)hipHostFree(hb); (void)hipHostFree(ho);
+        tk_pinned_put(hb); tk_pinned_put(ho);
         c->err = std::string("result copy failed: ") + hipGetErrorString(e);
         return TK_ERR_RUNTIME;
     }
@@ -1000,7 +1207,7 @@ extern "C" int tk_decode_batch(tk_ctx* c, const uint32_t* ids, const uint64_t* i
 
 extern "C" void tk_free_text_result(tk_text_result* r) {
     if (!r) return;
-    if (r->bytes) (void)hipHostFree(r->bytes);
-    if (r->offsets) (void)hipHostFree(r->offsets);
+    tk_pinned_put(r->bytes);
+    tk_pinned_put(r->offsets);
     memset(r, 0, sizeof(*r));
 }

@@ -370,10 +370,13 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     uint64_t blocks = (a.n_chunks + (TKF_BLOCK / 64) - 1) / (TKF_BLOCK / 64);
     // persistent waves, chunks strided over them: exactly the blocks that are resident at once, so that no partially
     // filled last round of blocks trails behind
-    static uint64_t cap = 0;
+    // (per device, like the merge grids below: a process may hold contexts on several GPUs)
+    static uint64_t cap_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint64_t& cap = cap_dev[dev & 63];
     if (cap == 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
+        int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         int per_cu = 0;   // resident blocks per CU: 8 (16 bytes per lane, 8 waves per SIMD) or 7 (32 bytes per lane: LDS)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tk_flat_kernel, TKF_BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;

@@ -12,6 +12,14 @@
 // mode 2: split only; mode 3: pass 1 over args.todo_list.  n_waves = waves launched (rounded up to whole 4-wave blocks)
 hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves, hipStream_t s);
 
+// One launch for a small batch (<= TK_SMALL_MAX_DOCS documents): encode + scan + pack by a single workgroup.  bytes /
+// out_ids / out_offs / status may be mapped pinned host memory.  status[0] != 0: a document needs pass 2, nothing usable
+// was written; status[1] = total ids.
+#define TK_SMALL_MAX_DOCS 1024
+#define TK_SMALL_MAX_BYTES (64u << 10)
+#define TK_SMALL_THREADS 1024
+hipError_t tk_launch_small(const TkEncodeArgs& args, uint32_t* out_ids, uint64_t* out_offs, uint32_t* status, hipStream_t s);
+
 // counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
 // ceil(n/2048)+1 u64.  offs[n] (= total) is also what the host reads back.
 hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s);
@@ -39,6 +47,7 @@ hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const 
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
 
 hipError_t tk_launch_iota(uint32_t* out, uint64_t n, hipStream_t s);   // out[i] = i
+hipError_t tk_launch_add_u64(uint64_t* p, uint64_t n, uint64_t add, hipStream_t s);   // p[i] += add
 
 // ---- 18-bit wire format of ids for the multi-GPU gather (tk_kernels.hip) ----
 hipError_t tk_launch_pack18(const uint32_t* ids, uint64_t n, void* packed, uint32_t* d_bad, hipStream_t s);

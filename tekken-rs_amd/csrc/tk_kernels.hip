@@ -39,6 +39,67 @@ hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves
 }
 
 // ------------------------------------------------------------------------------------------
+// Small batches in ONE launch (the reference's own call shape is one &str per call, src/tekkenizer.rs:378-405): a
+// single workgroup encodes up to TK_SMALL_MAX_DOCS documents (wave w takes documents w, w + n_waves, ...: the
+// per-document pass 1), scans their id counts and packs the ids in document order -- what the batch pipeline does with
+// about ten launches.  `bytes` may be mapped pinned host memory (a 64-byte string is read over PCIe by the kernel itself:
+// no copy engine in the path) and so may out_ids / out_offs / status; staging and counts are device memory.
+// status[0] = 1 if a document has to go to pass 2 (a piece that does not fit a window): the host then takes the batch
+// pipeline; status[1] = total ids.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TK_SMALL_THREADS) void tk_small_kernel(TkEncodeArgs a, uint32_t* __restrict__ out_ids,
+                                                                    uint64_t* __restrict__ out_offs, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_cnt[TK_SMALL_MAX_DOCS];
+    __shared__ uint32_t s_off[TK_SMALL_MAX_DOCS + 1];
+    __shared__ uint32_t s_defer;
+    const int lane = wv_lane();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_waves = TK_SMALL_THREADS / 64;
+    const uint32_t n_docs = (uint32_t)a.n_docs;
+    if (threadIdx.x == 0) s_defer = 0u;
+    __syncthreads();
+    const TkPolyPow pw = tk_poly_pow(a.t, lane);
+    for (uint32_t d = wv; d < n_docs; d += n_waves) {
+        const bool ok = tk_encode_doc<0>(a, (uint64_t)d, lane, pw);
+        if (!ok && lane == 0) s_defer = 1u;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (s_defer) {                                   // block-uniform
+        if (threadIdx.x == 0) { status[0] = 1u; status[1] = 0u; }
+        return;
+    }
+    for (uint32_t d = threadIdx.x; d < n_docs; d += TK_SMALL_THREADS) s_cnt[d] = a.counts[d];
+    __syncthreads();
+    if (wv == 0) {                                   // exclusive scan of up to TK_SMALL_MAX_DOCS counts by one wave
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < n_docs; base += 64u) {
+            const uint32_t d = base + (uint32_t)lane;
+            const uint32_t c = d < n_docs ? s_cnt[d] : 0u;
+            const uint32_t incl = wv_scan_incl_u32(c);
+            if (d < n_docs) s_off[d] = carry + incl - c;
+            carry += wv_readlane(incl, 63);
+        }
+        if (lane == 0) s_off[n_docs] = carry;
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d <= n_docs; d += TK_SMALL_THREADS) out_offs[d] = (uint64_t)s_off[d];
+    for (uint32_t d = wv; d < n_docs; d += n_waves) {
+        const uint32_t* src = a.staging + a.doc_offs[d] + 2ull * d;
+        uint32_t* dst = out_ids + s_off[d];
+        const uint32_t cnt = s_cnt[d];
+        for (uint32_t k = (uint32_t)lane; k < cnt; k += 64u) dst[k] = src[k];
+    }
+    if (threadIdx.x == 0) { status[0] = 0u; status[1] = s_off[n_docs]; }
+}
+
+hipError_t tk_launch_small(const TkEncodeArgs& args, uint32_t* out_ids, uint64_t* out_offs, uint32_t* status, hipStream_t s) {
+    if (args.n_docs > TK_SMALL_MAX_DOCS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_SMALL_THREADS), 0, s, args, out_ids, out_offs, status);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // exclusive scan of per-document counts (u32) into u64 offsets; 2048 counts per block
 // ------------------------------------------------------------------------------------------
 #define TK_SCAN_PER_THREAD 8
@@ -259,15 +320,19 @@ hipError_t tk_launch_wave_selftest(uint32_t* d_fail, hipStream_t s) {
 //   [ n x u16 low halves | padded to 4 bytes | ceil(n / 16) x u32, two high bits of 16 ids each ]
 // One thread per 16 ids (64 contiguous bytes in, 32 + 4 out); an id >= 2^18 raises *d_bad.
 // ------------------------------------------------------------------------------------------
+// The id buffers are only word-aligned in general (a rank's ids land at an arbitrary id index of the gathered buffer) and the
+// wire buffer is a caller's pointer: 16-byte accesses through vector types that promise 4-byte alignment only.
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) tk_u32x4_w;
+
 __global__ __launch_bounds__(256) void tk_pack18_kernel(const uint32_t* __restrict__ ids, uint64_t n, uint16_t* __restrict__ lows,
                                                         uint32_t* __restrict__ highs, uint32_t* __restrict__ d_bad) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, i0 = g * 16;
     if (i0 >= n) return;
     uint32_t v[16];
     if (i0 + 16 <= n) {
-        const uint4* src = reinterpret_cast<const uint4*>(ids + i0);
+        const tk_u32x4_w* src = reinterpret_cast<const tk_u32x4_w*>(ids + i0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+        for (int q = 0; q < 4; ++q) { const tk_u32x4_w x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = i0 + q < n ? ids[i0 + q] : 0u;
@@ -278,8 +343,8 @@ __global__ __launch_bounds__(256) void tk_pack18_kernel(const uint32_t* __restri
     if (over) atomicOr(d_bad, 1u);
     highs[g] = hi;
     if (i0 + 16 <= n) {
-        uint4* dst = reinterpret_cast<uint4*>(lows + i0);   // i0 is a multiple of 16: 32-byte aligned
-        uint4 a, b;
+        tk_u32x4_w* dst = reinterpret_cast<tk_u32x4_w*>(lows + i0);   // 32 i0 bytes into a word-aligned buffer
+        tk_u32x4_w a, b;
         a.x = (v[0] & 0xFFFFu) | (v[1] << 16); a.y = (v[2] & 0xFFFFu) | (v[3] << 16); a.z = (v[4] & 0xFFFFu) | (v[5] << 16); a.w = (v[6] & 0xFFFFu) | (v[7] << 16);
         b.x = (v[8] & 0xFFFFu) | (v[9] << 16); b.y = (v[10] & 0xFFFFu) | (v[11] << 16); b.z = (v[12] & 0xFFFFu) | (v[13] << 16); b.w = (v[14] & 0xFFFFu) | (v[15] << 16);
         dst[0] = a; dst[1] = b;
@@ -294,13 +359,13 @@ __global__ __launch_bounds__(256) void tk_unpack18_kernel(const uint16_t* __rest
     if (i0 >= n) return;
     const uint32_t hi = highs[g];
     if (i0 + 16 <= n) {
-        const uint4* src = reinterpret_cast<const uint4*>(lows + i0);
-        const uint4 a = src[0], b = src[1];
+        const tk_u32x4_w* src = reinterpret_cast<const tk_u32x4_w*>(lows + i0);
+        const tk_u32x4_w a = src[0], b = src[1];
         const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint4* dst = reinterpret_cast<uint4*>(ids + i0);
+        tk_u32x4_w* dst = reinterpret_cast<tk_u32x4_w*>(ids + i0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 o;
+            tk_u32x4_w o;
             o.x = (w[2 * q] & 0xFFFFu) | (((hi >> (8 * q)) & 3u) << 16);
             o.y = (w[2 * q] >> 16) | (((hi >> (8 * q + 2)) & 3u) << 16);
             o.z = (w[2 * q + 1] & 0xFFFFu) | (((hi >> (8 * q + 4)) & 3u) << 16);
@@ -327,6 +392,17 @@ hipError_t tk_launch_unpack18(const void* packed, uint64_t n, uint32_t* ids, hip
     const uint32_t* highs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(packed) + ((2 * n + 3) & ~3ull));
     const uint64_t groups = (n + 15) / 16;
     hipLaunchKernelGGL(tk_unpack18_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, s, lows, highs, n, ids);
+    return hipGetLastError();
+}
+
+// p[i] += add (the node-level gather rebases a run's id offsets to batch offsets)
+__global__ __launch_bounds__(256) void tk_add_u64_kernel(uint64_t* __restrict__ p, uint64_t n, uint64_t add) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] += add;
+}
+hipError_t tk_launch_add_u64(uint64_t* p, uint64_t n, uint64_t add, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_add_u64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, p, n, add);
     return hipGetLastError();
 }
 

@@ -292,7 +292,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
 // table cache (row f-2)
 // ------------------------------------------------------------------------------------------
 #define TK_CACHE_MAGIC 0x42544B54u /* "TKTB" */
-#define TK_CACHE_VERSION 4u        /* bump whenever a table layout or a hash function changes */
+#define TK_CACHE_VERSION 5u        /* bump whenever a table layout or a hash function changes */
 
 static uint64_t fnv1a64(uint64_t h, const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;
@@ -309,17 +309,21 @@ uint64_t tk_tables_key(const uint8_t* blob, const uint32_t* offs, uint32_t n_ran
 }
 
 namespace {
+// (every vector goes through the running payload checksum `sum`, which is the file's tail)
 template <class T>
-bool put_vec(FILE* f, const std::vector<T>& v) {
+bool put_vec(FILE* f, const std::vector<T>& v, uint64_t& sum) {
     const uint64_t n = v.size();
+    sum = tk_sum64(tk_sum64(sum, &n, 8), v.data(), n * sizeof(T));
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
 }
 template <class T>
-bool get_vec(FILE* f, std::vector<T>& v, uint64_t max_elems) {
+bool get_vec(FILE* f, std::vector<T>& v, uint64_t max_elems, uint64_t& sum) {
     uint64_t n = 0;
     if (fread(&n, 8, 1, f) != 1 || n > max_elems) return false;
     v.resize(n);
-    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+    if (!(n == 0 || fread(v.data(), sizeof(T), n, f) == n)) return false;
+    sum = tk_sum64(tk_sum64(sum, &n, 8), v.data(), n * sizeof(T));
+    return true;
 }
 struct CacheHead {
     uint32_t magic, version;
@@ -340,11 +344,12 @@ bool tk_tables_save(const TkHostTables& t, uint64_t key, const std::string& path
     h.key_hash_mode = t.key_hash_mode; h.n_ranks = t.n_ranks; h.num_special = t.num_special; h.bos_id = t.bos_id; h.eos_id = t.eos_id;
     h.p1inv = t.p1inv; h.p2inv = t.p2inv;
     h.n_pairs = t.n_pairs; h.n_key = t.n_key; h.n_long = t.n_long; h.n_key_second = t.n_key_second; h.n_key_spill_slots = t.n_key_spill_slots;
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && put_vec(f, t.blob) && put_vec(f, t.offs) && put_vec(f, t.uc_stage1) &&
-              put_vec(f, t.uc_stage2) && put_vec(f, t.key8_tab) && put_vec(f, t.key_tab) && put_vec(f, t.long_tab) &&
-              put_vec(f, t.pair_tab) && put_vec(f, t.pair2);
-    const uint32_t tail = TK_CACHE_MAGIC;   // a truncated file has no tail
-    ok = ok && fwrite(&tail, 4, 1, f) == 1;
+    uint64_t sum = tk_sum64(key, &h, sizeof(h));
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && put_vec(f, t.blob, sum) && put_vec(f, t.offs, sum) && put_vec(f, t.uc_stage1, sum) &&
+              put_vec(f, t.uc_stage2, sum) && put_vec(f, t.key8_tab, sum) && put_vec(f, t.key_tab, sum) && put_vec(f, t.long_tab, sum) &&
+              put_vec(f, t.pair_tab, sum) && put_vec(f, t.pair2, sum);
+    const uint32_t tail = TK_CACHE_MAGIC;   // a truncated file has no tail; a damaged one a wrong checksum
+    ok = ok && fwrite(&sum, 8, 1, f) == 1 && fwrite(&tail, 4, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
     if (!ok) remove(tmp.c_str());
@@ -358,10 +363,12 @@ bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path) {
     TkHostTables x;
     const uint64_t lim = 1ull << 31;
     uint32_t tail = 0;
-    bool ok = fread(&h, sizeof(h), 1, f) == 1 && h.magic == TK_CACHE_MAGIC && h.version == TK_CACHE_VERSION && h.key == key &&
-              get_vec(f, x.blob, lim) && get_vec(f, x.offs, lim) && get_vec(f, x.uc_stage1, lim) && get_vec(f, x.uc_stage2, lim) &&
-              get_vec(f, x.key8_tab, lim) && get_vec(f, x.key_tab, lim) && get_vec(f, x.long_tab, lim) && get_vec(f, x.pair_tab, lim) &&
-              get_vec(f, x.pair2, lim) && fread(&tail, 4, 1, f) == 1 && tail == TK_CACHE_MAGIC;
+    uint64_t sum = 0, want = 0;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && h.magic == TK_CACHE_MAGIC && h.version == TK_CACHE_VERSION && h.key == key;
+    if (ok) sum = tk_sum64(key, &h, sizeof(h));
+    ok = ok && get_vec(f, x.blob, lim, sum) && get_vec(f, x.offs, lim, sum) && get_vec(f, x.uc_stage1, lim, sum) && get_vec(f, x.uc_stage2, lim, sum) &&
+         get_vec(f, x.key8_tab, lim, sum) && get_vec(f, x.key_tab, lim, sum) && get_vec(f, x.long_tab, lim, sum) && get_vec(f, x.pair_tab, lim, sum) &&
+         get_vec(f, x.pair2, lim, sum) && fread(&want, 8, 1, f) == 1 && want == sum && fread(&tail, 4, 1, f) == 1 && tail == TK_CACHE_MAGIC;
     fclose(f);
     if (!ok) return false;
     // sizes must agree with the masks the kernels index with

@@ -73,4 +73,24 @@ bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path);
 int tk_build_tables_cached(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, uint32_t bos_id,
                            uint32_t eos_id, TkHostTables& out, std::string& err, bool* from_cache);
 
+// 64-bit checksum of a byte range, chained through `seed` (four independent multiply-mix lanes: memory speed).  The side
+// files of the loader cache end with the checksum of their payload: a flipped bit anywhere makes the file "not check out",
+// so it is ignored and rewritten -- a cache can change load time, never a result.
+inline uint64_t tk_sum64(uint64_t seed, const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    uint64_t h[4] = {seed ^ 0xCBF29CE484222325ull, seed + 0x9E3779B97F4A7C15ull, seed ^ 0xD6E8FEB86659FD93ull, seed + 0xA0761D6478BD642Full};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int l = 0; l < 4; ++l) {
+            uint64_t w;
+            __builtin_memcpy(&w, b + i + 8 * l, 8);
+            h[l] = (h[l] ^ w) * 0x100000001B3ull;
+            h[l] ^= h[l] >> 29;
+        }
+    for (; i < n; ++i) { h[0] = (h[0] ^ b[i]) * 0x100000001B3ull; h[0] ^= h[0] >> 29; }
+    uint64_t x = h[0] ^ (h[1] * 0x9E3779B97F4A7C15ull) ^ (h[2] >> 7) ^ (h[3] << 9) ^ (uint64_t)n;
+    x ^= x >> 31; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 33;
+    return x;
+}
+
 #endif

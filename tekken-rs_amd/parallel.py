@@ -97,6 +97,11 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
     if on_gpu and not wait:
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
+        # The caller's tensors are consumed on the side stream: tell the caching allocator, or a block freed on the main
+        # stream right after this call (bench.py passes a temporary clone) could be handed out again while the side-stream
+        # copy / send is still pending.
+        local_ids.record_stream(side)
+        local_doc_counts.record_stream(side)
 
     def on_side(after_main=True):
         if side is None:
@@ -144,6 +149,9 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
                 torch.cumsum(counts, 0, out=offs[1:])
             if side is not None:
                 side.synchronize()
+                # allocated under the side stream, used (and eventually freed) by the caller on the main stream
+                ids.record_stream(main)
+                offs.record_stream(main)
             return ids, offs
 
         return finish_root() if wait else PendingGather(finish_root)

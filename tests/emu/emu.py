@@ -12,8 +12,9 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libtk_emu.so"])
-        L = ctypes.CDLL(os.path.join(_HERE, "libtk_emu.so"))
+        name = "libtk_emu_asan.so" if os.environ.get("TK_TEST_SANITIZE") else "libtk_emu.so"   # tests/test_sanitizers.py
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
+        L = ctypes.CDLL(os.path.join(_HERE, name))
         u8p = ctypes.POINTER(ctypes.c_uint8)
         u32p = ctypes.POINTER(ctypes.c_uint32)
         u64p = ctypes.POINTER(ctypes.c_uint64)

@@ -419,6 +419,21 @@ def test_ids18_wire_format(tk, eng_small):
         torch.cuda.synchronize()
         out = d_out.cpu().numpy()
         assert np.array_equal(out[:n].view(np.uint32), ids) and out[n] == -1
+        # id buffers that are only word-aligned (a rank's ids land at an arbitrary id index of the gathered buffer; per-rank
+        # id counts are not multiples of 4): pack from / unpack to every offset 1..3
+        for sh in (1, 2, 3):
+            if n == 0:
+                continue
+            src = torch.zeros(n + sh, dtype=torch.int32, device="cuda")
+            src[sh:] = d_ids
+            d_p2 = torch.zeros_like(d_packed)
+            eng_small.pack_ids18_device(src.data_ptr() + 4 * sh, n, d_p2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert torch.equal(d_p2, d_packed)
+            dst = torch.full((n + sh + 1,), -1, dtype=torch.int32, device="cuda")
+            eng_small.unpack_ids18_device(d_packed.data_ptr(), n, dst.data_ptr() + 4 * sh, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            o2 = dst.cpu().numpy()
+            assert np.array_equal(o2[sh:sh + n].view(np.uint32), ids) and o2[sh + n] == -1 and (o2[:sh] == -1).all()
     bad = torch.tensor([5, 1 << 18, 7], dtype=torch.int32, device="cuda")
     buf = torch.zeros(16, dtype=torch.int32, device="cuda")
     with pytest.raises(tk.TokenizerError):
@@ -476,6 +491,27 @@ def test_json_pattern_opt_in(tk, test_vocab, bench_vocab):
     t.set_honour_pattern(False)
     assert t.encode("HelloWorld 12", False, False) == plain.encode(b"HelloWorld 12", False, False)
     t.close()
+    # ... also when the object comes from a TK_TABLE_CACHE_DIR side file (the side file keeps config.pattern)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.json")
+        with open(path, "w") as f:
+            json.dump(m, f)
+        old = os.environ.get("TK_TABLE_CACHE_DIR")
+        os.environ["TK_TABLE_CACHE_DIR"] = td
+        try:
+            t1 = tk.Tekkenizer.from_file(path, device=0)
+            t2 = tk.Tekkenizer.from_file(path, device=0)
+        finally:
+            if old is None:
+                del os.environ["TK_TABLE_CACHE_DIR"]
+            else:
+                os.environ["TK_TABLE_CACHE_DIR"] = old
+        assert not t1.from_cache() and t2.from_cache() and t2.json_pattern() == sv.MISTRAL_PATTERN
+        t2.set_honour_pattern(True)
+        assert t2.encode("HelloWorld 12", False, False) == orc.encode(b"HelloWorld 12", False, False)
+        t1.close()
+        t2.close()
     m["config"]["pattern"] = "something else"
     t = tk.Tekkenizer.from_json(json.dumps(m), device=0)
     with pytest.raises(tk.TokenizerError) as ei:
@@ -511,3 +547,62 @@ def test_merge_kernels_every_piece_length(tk, eng_small, eng_bench, test_vocab, 
         orc = helpers.oracle_for(v)
         for bos, eos in ((True, True), (False, False)):
             check_batch(eng, orc, data, offs, bos, eos)
+
+
+def test_small_batches_one_launch(tk, test_vocab, bench_vocab):
+    """tk_encode_one and small tk_encode_batch calls (<= 1024 documents, <= 64 KiB) run as ONE launch (tk_small_kernel);
+    ids identical to the oracle, a document that needs pass 2 falls back,
+    the capacity check, every BOS / EOS combination, a batch just over either limit takes the pipeline."""
+    for v in (test_vocab, bench_vocab):
+        orc = helpers.oracle_for(v)
+        e = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
+        docs = [d for d in helpers.mixed_docs(30, 6, 30, max_len=3000) + helpers.random_unicode_docs(120) if len(d) <= 3000]
+        n0 = e.small_path_calls()
+        for i, d in enumerate(docs):
+            bos, eos = bool(i & 1), bool(i & 2)
+            got = e.encode_one(d, bos, eos).tolist()
+            assert got == orc.encode(d, bos, eos), d[:80]
+        served = e.small_path_calls() - n0
+        assert served >= len(docs) - 15         # all but the few with a piece that does not fit a window
+        # C1 shape: 1 000 x 64-byte ASCII strings, one call each (BASELINE configs[0])
+        data, offs = corpus.generate("ascii", 1000, 64, seed=corpus.BASE_SEED)
+        for d in corpus.docs_of(data, offs)[:300]:
+            assert e.encode_one(d, True, True).tolist() == orc.encode(d, True, True)
+        # small batches through tk_encode_batch
+        n1 = e.small_path_calls()
+        for n_docs in (1, 2, 17, 64, 200, 1024):
+            sub = corpus.docs_of(data, offs)[:n_docs]
+            if n_docs == 200:
+                sub = sub[:100] + [b"", "é中".encode() * 5, b" " * 40, b"\n"] + sub[100:196]
+            assert e.encode_docs(sub, True, False, validate_utf8=True) == [orc.encode(d, True, False) for d in sub]
+        assert e.small_path_calls() - n1 == 6
+        # over the limits: the batch pipeline (same ids)
+        n2 = e.small_path_calls()
+        many = corpus.docs_of(data, offs)[:1000] + [b"x"] * 30
+        assert e.encode_docs(many, False, False) == [orc.encode(d, False, False) for d in many]
+        big = [b"word " * 14000]                                      # 70 000 bytes
+        assert e.encode_docs(big, False, True) == [orc.encode(big[0], False, True)]
+        assert e.small_path_calls() == n2
+        # a piece that does not fit a window: falls back to the pipeline, same ids
+        longp = b"q" * 300 + b" tail"
+        assert e.encode_one(longp, True, True).tolist() == orc.encode(longp, True, True)
+        # invalid UTF-8 is reported on this path too
+        with pytest.raises(tk.TokenizerError):
+            e.encode_docs([b"ok", b"\xff\xfe"], False, False, validate_utf8=True)
+        # capacity
+        out = np.empty(3, np.uint32)
+        with pytest.raises(tk.TokenizerError):
+            e.encode_one(b"one two three four five six", True, True, out=out)
+        e.close()
+
+
+def test_tokenizer_encode_uses_one_launch(tk, bench_vocab):
+    t = tk.Tekkenizer.from_file(bench_vocab["path"], device=0)
+    orc = helpers.oracle_for(bench_vocab)
+    eng = t.engine()
+    n0 = eng.small_path_calls()
+    for text in ("Hello, world!", "", "it's 12345 ...", "日本語 のテキスト"):
+        for bos, eos in ((False, False), (True, True)):
+            assert t.encode(text, bos, eos) == orc.encode(text.encode("utf-8"), bos, eos)
+    assert eng.small_path_calls() - n0 == 8
+    t.close()

@@ -209,7 +209,9 @@ def test_model_cache_from_file(tk, small_vocab, bench_vocab, tmp_path, monkeypat
     assert len(side) == 1
     second = tk.Tekkenizer.from_file(str(f1), device=-1)      # from the side file
     ids = [1, 266, 42, 129, 121, 124, 118, 110, 4, 2]
+    assert not plain.from_cache() and not first.from_cache() and second.from_cache()
     for t in (first, second):
+        assert t.json_pattern() == plain.json_pattern() == "ignored"       # config.pattern survives the side file
         assert (t.vocab_size(), t.num_special_tokens(), t.version()) == (plain.vocab_size(), plain.num_special_tokens(), plain.version())
         assert t.get_control_token("é☃") == 4 and t.get_control_token("<SPECIAL_7>") == 7
         assert t.decode(ids, P.Keep) == plain.decode(ids, P.Keep) == "<s>hello worldé☃</s>"
@@ -240,9 +242,9 @@ def test_model_cache_from_file(tk, small_vocab, bench_vocab, tmp_path, monkeypat
     t1 = time.perf_counter()
     b = tk.Tekkenizer.from_file(bench_vocab["path"], device=-1)
     t2 = time.perf_counter()
-    print("from_file host-only: parse %.3f s, from cache %.3f s" % (t1 - t0, t2 - t1))
+    print("from_file host-only: parse %.3f s, from cache %.3f s" % (t1 - t0, t2 - t1))   # (printed, not asserted: shared CI box)
     assert a.vocab_size() == b.vocab_size() and a.id_to_piece(100000) == b.id_to_piece(100000)
-    assert (t2 - t1) < (t1 - t0)
+    assert not a.from_cache() and b.from_cache() and a.json_pattern() == b.json_pattern() != ""
 
 
 def test_honour_pattern_needs_device_and_known_pattern(tk, small):
@@ -251,3 +253,38 @@ def test_honour_pattern_needs_device_and_known_pattern(tk, small):
     with pytest.raises(tk.TokenizerError) as e:
         small.set_honour_pattern(True)
     assert e.value.kind in ("NoDevice", "Tokenizers", "InvalidConfig")
+
+
+def test_fewer_than_256_ranks_host_only_yes_device_no(tk, small_vocab):
+    """A documented divergence.  The reference constructs a Tekkenizer from a rank table with fewer than 256 entries
+    (reload_mergeable_ranks only checks the byte tokens that ARE there, src/tekkenizer.rs:793-798) and then panics inside
+    tiktoken-rs on the first text byte whose single-byte token is missing.  Here the host-side mirror loads such a file
+    like the reference does (loader, accessors, decode work), but a DEVICE context is refused at construction with
+    InvalidConfig: the kernels take the rank of a single byte from the byte itself and have no panic to mirror."""
+    import ctypes
+    import numpy as np
+    toks = small_vocab["tokens"][:100]
+    t = tk.Tekkenizer.from_json(json.dumps(model(toks)), device=-1)
+    assert t.vocab_size() == 110 and t.decode([10 + 65], tk.SpecialTokenPolicy.Ignore) == "A"
+    t.close()
+    blob = np.frombuffer(b"".join(toks), dtype=np.uint8).copy()
+    offs = np.arange(len(toks) + 1, dtype=np.uint32)
+    h = ctypes.c_void_p()
+    rc = tk.lib().tk_ctx_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                len(toks), 10, 1, 2, 0, ctypes.byref(h))
+    assert rc == tk.TK_ERR_INVALID_CONFIG and b"256 single-byte" in tk.lib().tk_last_error(None)
+
+
+def test_node_create_argument_checks(tk, small_vocab):
+    """tk_node_create (csrc/tk_node.cpp): the device list is checked before any device is touched -- the same GPU listed
+    twice is refused cleanly, as is an empty / oversized list; without a GPU a valid list fails with NoDevice (no CPU fallback)."""
+    v = small_vocab
+    for devs in ((0, 0), (1, 0, 1), ()):
+        with pytest.raises(tk.TokenizerError) as e:
+            tk.Node(v["tokens"], v["num_special"], v["bos"], v["eos"], devices=devs)
+        assert e.value.kind == "InvalidConfig"           # TK_ERR_INVALID_ARG
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(tk.TokenizerError) as e:
+            tk.Node(v["tokens"], v["num_special"], v["bos"], v["eos"], devices=(0,))
+        assert e.value.kind in ("NoDevice", "Tokenizers")

@@ -52,6 +52,13 @@ def generate(kind, n_docs, doc_len=512, seed=BASE_SEED, first_doc=0, threads=Non
     return data[:total], offs
 
 
+def offsets(kind, n_docs, doc_len=512, seed=BASE_SEED, first_doc=0):
+    """uint64[n_docs+1] document offsets alone (lengths are a function of the seed and the document index)."""
+    offs = np.zeros(n_docs + 1, np.uint64)
+    lib().tkc_fill_offsets(KINDS[kind], seed, first_doc, n_docs, doc_len, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    return offs
+
+
 def words():
     L = lib()
     return [L.tkc_word(i).decode() for i in range(L.tkc_n_words())]

@@ -432,16 +432,22 @@ def cpu_baseline(args, data, offs, vocab_path, ids, oo, n_bytes):
         dt += tk_oracle.last_batch_seconds() / args.cpu_passes       # the C loop alone
     cpu_mbs = int(offs[m]) / 1e6 / dt
     exact = bool(np.array_equal(oo[:m + 1], eoo) and np.array_equal(ids[:int(oo[m])], eids))
-    nt = {}
+    # what the vocabulary does to this corpus: the share of pieces that are not vocabulary keys is the merge kernels' workload
+    k = min(m, 20000)
+    st = orc.miss_stats(data[:int(offs[k])], offs[:k + 1])
+    nt = {"vocab_fit": {"sample_docs": k, "pieces": st["pieces"], "miss_rate": round(st["missed"] / max(1, st["pieces"]), 4),
+                        "mean_missed_piece_bytes": round(st["missed_bytes"] / max(1, st["missed"]), 2),
+                        "mean_ids_per_missed_piece": round(st["missed_ids"] / max(1, st["missed"]), 2),
+                        "bytes_per_piece": round(int(offs[k]) / max(1, st["pieces"]), 2)}}
     threads = args.cpu_threads or min(os.cpu_count() or 1, 256)
     if threads > 1:
         # BASELINE.md row CPU-restate-NT: the same restatement on N threads (documents striped), N stated
         orc.encode_batch(sub, sub_offs, True, True, threads=threads)     # (first pass: page faults of the staging buffer)
         orc.encode_batch(sub, sub_offs, True, True, threads=threads)
         dtn = tk_oracle.last_batch_seconds()
-        nt = {"cpu_baseline_nt": {"value": round(int(offs[m]) / 1e6 / dtn, 1), "unit": "MB/s", "cores": threads, "kind": "port",
+        nt["cpu_baseline_nt"] = {"value": round(int(offs[m]) / 1e6 / dtn, 1), "unit": "MB/s", "cores": threads, "kind": "port",
                                   "sample": "the same %d docs, second of 2 passes: %.3f s, oracle/tk_oracle.c on %d threads; host has %d cores"
-                                            % (m, dtn, threads, os.cpu_count() or 0)}}
+                                            % (m, dtn, threads, os.cpu_count() or 0)}
     return dict(nt, **{"cpu_baseline": {"value": round(cpu_mbs, 1), "unit": "MB/s", "cores": 1, "kind": "port",
                              "sample": "%d docs (%d bytes) of the same workload, %d passes of %.1f s, oracle/tk_oracle.c single thread; host has %d cores"
                                        % (m, int(offs[m]), args.cpu_passes, dt, os.cpu_count() or 0)},

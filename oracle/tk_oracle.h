@@ -61,6 +61,9 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
  * CPU baseline (1 thread) and as cpu_baseline_nt (n_threads > 1). */
 double tk_oracle_last_batch_seconds(void);
 
+/* out[4] = {pieces, pieces that miss the vocabulary, bytes of those, ids they produce} over a packed batch. */
+void tk_oracle_miss_stats(const tk_oracle* o, const uint8_t* bytes, const uint64_t* offs, uint64_t n_docs, uint64_t* out);
+
 /* 2-bit class of a code point: 0=O 1=L 2=N 3=S (tables generated from Python `regex`). */
 int tk_oracle_class(uint32_t cp);
 

@@ -49,6 +49,7 @@ def lib():
         L.tk_oracle_class.restype = ctypes.c_int
         L.tk_oracle_class.argtypes = [ctypes.c_uint32]
         L.tk_oracle_last_batch_seconds.restype = ctypes.c_double
+        L.tk_oracle_miss_stats.argtypes = [ctypes.c_void_p, u8p, u64p, ctypes.c_uint64, u64p]
         L.tk_oracle_fnv1a.restype = ctypes.c_uint64
         L.tk_oracle_fnv1a.argtypes = [u32p, ctypes.c_uint64]
         _LIB = L
@@ -113,6 +114,15 @@ class Oracle:
         k = lib().tk_oracle_encode(self._h, _p(buf, ctypes.c_uint8), n, int(add_bos), int(add_eos),
                                    _p(out, ctypes.c_uint32), n + 2)
         return out[:k].tolist()
+
+    def miss_stats(self, data: np.ndarray, offs: np.ndarray):
+        """{pieces, missed (not a vocabulary key), missed_bytes, missed_ids} of a packed batch."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        out = np.zeros(4, np.uint64)
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        lib().tk_oracle_miss_stats(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1, _p(out, ctypes.c_uint64))
+        return {"pieces": int(out[0]), "missed": int(out[1]), "missed_bytes": int(out[2]), "missed_ids": int(out[3])}
 
     def encode_batch(self, data: np.ndarray, offs: np.ndarray, add_bos=True, add_eos=True, threads=1):
         """data: uint8[n_bytes], offs: uint64[D+1] -> (ids uint32[T], out_offs uint64[D+1])."""

@@ -402,7 +402,9 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, c->f_mcnt.reserve((5 * n_chunks + 1) * 4));   // 4 C miss counts (class-major) | C slot counts (one scan)
     TK_HIP(c, c->f_mpfx.reserve((5 * n_chunks + 2) * 8));
     TK_HIP(c, c->f_info.reserve((n_docs + 1) * 16));
-    TK_HIP(c, c->f_wfirst.reserve((n_chunks * (TKF_MISSOFF2 / 64 + 1) + 64) * 4));   // one entry per 64 queued pieces of 2..16 bytes
+    // one entry per 64 queued pieces: the narrow classes (2..16 bytes), then the wide ones (17..64 bytes)
+    const uint64_t wf_narrow = n_chunks * (TKF_MISSOFF2 / 64 + 1) + 64, wf_wide = n_chunks * ((TKF_MISSCAP - TKF_MISSOFF2) / 64 + 1) + 64;
+    TK_HIP(c, c->f_wfirst.reserve((wf_narrow + wf_wide) * 4));
     TK_HIP(c, c->counts.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->out_offs.reserve((n_docs + 1) * 8));
     const uint64_t scan_n = n_docs > 5 * n_chunks ? n_docs : 5 * n_chunks;
@@ -425,6 +427,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.miss_prefix = (const uint64_t*)c->f_mpfx.p;
     fa.holes = (uint32_t*)c->f_flags.p + (n_docs + 1);
     fa.wave_first = (uint32_t*)c->f_wfirst.p;
+    fa.wave_first_wide = (uint32_t*)c->f_wfirst.p + wf_narrow;
     fa.t = c->dview;
     fa.pattern = c->pattern;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments

@@ -94,14 +94,19 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_dbg_kernel(TkFlatAr
     else tk_flat_kernel_body<1, 1>(a, lds_all);
 }
 
-// wave w of tk_merge_kernel starts with item 64 w: note down which sub-queue holds it (thread e owns the waves whose
-// first item falls into sub-queue e), so that the merge waves do not have to search the prefix sums
-__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uint64_t* __restrict__ prefix, uint64_t n_e,
-                                                                        uint32_t* __restrict__ wave_first) {
+// wave w of tk_merge_kernel starts with item 64 w of the narrow classes, wave w of tk_merge_wide_kernel with item 64 w of
+// the wide ones: note down which sub-queue holds it (thread e owns the waves whose first item falls into sub-queue e), so
+// that the merge waves do not have to search the prefix sums
+__global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uint64_t* __restrict__ prefix, uint64_t n_chunks,
+                                                                        uint32_t* __restrict__ wave_first,
+                                                                        uint32_t* __restrict__ wave_first_wide) {
     const uint64_t e = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
-    if (e >= n_e) return;
-    const uint64_t lo = prefix[e], hi = prefix[e + 1];
-    for (uint64_t w = (lo + 63) / 64; w * 64 < hi; ++w) wave_first[w] = (uint32_t)e;
+    if (e >= 4 * n_chunks) return;
+    const bool wide = e >= 2 * n_chunks;
+    const uint64_t first = wide ? prefix[2 * n_chunks] : 0;
+    const uint64_t lo = prefix[e] - first, hi = prefix[e + 1] - first;
+    uint32_t* out = wide ? wave_first_wide : wave_first;
+    for (uint64_t w = (lo + 63) / 64; w * 64 < hi; ++w) out[w] = (uint32_t)e;
 }
 
 // persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are).
@@ -419,8 +424,8 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     uint64_t b1 = (a.n_chunks * 4 + TKM_BLOCK / 64 - 1) / (TKM_BLOCK / 64), b2 = (a.n_chunks + TKM_WIDE_BLOCK / 64 - 1) / (TKM_WIDE_BLOCK / 64);
     if (b1 > res1) b1 = res1;
     if (b2 > res2) b2 = res2;
-    hipLaunchKernelGGL(tk_merge_wavefirst_kernel, dim3(tkf_blocks(2 * a.n_chunks)), dim3(TKF_BLOCK), 0, s, a.miss_prefix,
-                       2 * a.n_chunks, a.wave_first);
+    hipLaunchKernelGGL(tk_merge_wavefirst_kernel, dim3(tkf_blocks(4 * a.n_chunks)), dim3(TKF_BLOCK), 0, s, a.miss_prefix,
+                       a.n_chunks, a.wave_first, a.wave_first_wide);
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKM_BLOCK), TKM_LDS_BYTES, s, a);
     hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKM_WIDE_BLOCK), TKM_WIDE_LDS_BYTES, s, a);
     return hipGetLastError();

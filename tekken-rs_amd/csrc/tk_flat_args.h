@@ -43,7 +43,8 @@ struct TkFlatArgs {
                                  // sub-queue of length class k at TKF_MISSOFFk
     uint32_t* miss_count;        // [4 * n_chunks] class-major: queued pieces of class k of chunk c at [k * n_chunks + c]
     const uint64_t* miss_prefix; // [4 * n_chunks + 1] exclusive prefix sums of miss_count (the merge kernels' item order)
-    uint32_t* wave_first;        // [narrow items / 64 + 1] sub-queue that holds item 64 w (tk_merge_wavefirst_kernel)
+    uint32_t* wave_first;        // [narrow items / 64 + 1] sub-queue that holds item 64 w of the narrow classes (tk_merge_wavefirst_kernel)
+    uint32_t* wave_first_wide;   // [wide items / 64 + 1] the same for the wide classes (items counted from the first wide one)
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags

@@ -890,10 +890,11 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint3
     const uint64_t item = item0 + (uint64_t)lane;
     const bool have = item < total;
     uint64_t cl = 0, pcl = 0;                         // the lane's sub-queue and its first item
-    if (!WIDE) {
-        // the wave's first sub-queue was written down by tk_merge_wavefirst_kernel; the sub-queues of the 64 items
-        // follow from ONE coalesced load of the next 64 prefix sums and a binary search across the lanes (bpermute)
-        uint64_t base = a.wave_first[wave_id];        // prefix[base] <= item0
+    {
+        // the wave's first sub-queue was written down by tk_merge_wavefirst_kernel (one table for the narrow classes, one
+        // for the wide ones); the sub-queues of the 64 items follow from ONE coalesced load of the next 64 prefix sums and
+        // a binary search across the lanes (bpermute)
+        uint64_t base = (WIDE ? a.wave_first_wide : a.wave_first)[wave_id];        // prefix[base] <= item0
         uint64_t pbase = prefix[base];
         bool done = !have;
         for (;;) {
@@ -919,34 +920,6 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint3
             // all 64 sub-queues start at or below some lane's item (sparse queues): go on with the next 64
             pbase = ((uint64_t)wv_shfl((uint32_t)(pf >> 32), 63) << 32) | wv_shfl((uint32_t)pf, 63);
             base += 64;
-        }
-    } else {
-        // sub-queue of the wave's first item: 64-ary search over the prefix sums, one probe per lane and step
-        uint64_t lo = 0, hi = n_e;                        // invariant: prefix[lo] <= item0 < prefix[hi]
-        while (hi - lo > 1) {
-            const uint64_t step = (hi - lo + 63) / 64;
-            const uint64_t q = lo + (uint64_t)lane * step;
-            const bool le = q < hi && prefix[q] <= item0;
-            const uint64_t LE = wv_ballot(le);            // a prefix of the lanes (lane 0 always)
-            const int top = tk_msb64(LE);
-            const uint64_t nlo = lo + (uint64_t)top * step;
-            const uint64_t nhi = nlo + step < hi ? nlo + step : hi;
-            lo = nlo;
-            hi = nhi;
-        }
-        // every lane: the sub-queue of its own item, searched from the wave's first one on
-        uint64_t ch = lo + 64 < n_e ? lo + 64 : n_e;      // prefix[cl] <= item < prefix[ch]
-        cl = lo;
-        if (have) {
-            while (prefix[ch] <= item) {                  // never past n_e: prefix[n_e] >= total > item
-                cl = ch;
-                ch = ch + 64 < n_e ? ch + 64 : n_e;
-            }
-            while (ch - cl > 1) {
-                const uint64_t mid = (cl + ch) / 2;
-                if (prefix[mid] <= item) cl = mid; else ch = mid;
-            }
-            pcl = prefix[cl];
         }
     }
     uint32_t rec = 0;

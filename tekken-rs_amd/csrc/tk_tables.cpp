@@ -160,12 +160,22 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
     {
         std::vector<KeyEnt> e8, e16;
         for (const KeyEnt& e : key_entries) (e.len <= 8 ? e8 : e16).push_back(e);
+        // Placement is frequency-aware: `ents` come in rank order (merge order = how common a token is).  First every key
+        // whose FIRST choice is still free takes it, lower ranks first; only then the others take their second choice or
+        // kick -- and a kick moves the RARER of the two residents.  So the tokens that make up most of any text sit in their
+        // first choice, and a wave of 64 probes seldom has a lane that needs the second fetch (the second-fetch code is
+        // per wave, not per lane: before this ~0.9 of the batches of the flat kernel ran it).
         auto place = [&](const std::vector<KeyEnt>& ents, uint32_t mode, uint32_t cap, std::vector<KeyEnt>& tab) -> bool {
             const uint32_t mask = cap - 1;
             tab.assign(cap, KeyEnt{{0, 0, 0, 0}, 0, 0});
+            std::vector<const KeyEnt*> later;
+            for (const KeyEnt& e : ents) {
+                const uint32_t s1 = tk_key_hash(mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len) & mask;
+                if (tab[s1].len == 0) tab[s1] = e; else later.push_back(&e);
+            }
             uint32_t rnd = 0x9E3779B9u;
-            for (const KeyEnt& e0 : ents) {
-                KeyEnt e = e0;
+            for (const KeyEnt* e0 : later) {
+                KeyEnt e = *e0;
                 uint32_t avoid = 0xFFFFFFFFu;
                 for (int kicks = 0;; ++kicks) {
                     const uint32_t h = tk_key_hash(mode, e.k[0], e.k[1], e.k[2], e.k[3], e.len);
@@ -174,7 +184,10 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
                     if (tab[s2].len == 0) { tab[s2] = e; break; }
                     if (kicks >= 500) return false;
                     rnd = rnd * 1664525u + 1013904223u;
-                    uint32_t victim = (rnd >> 16) & 1u ? s2 : s1;
+                    // the rarer resident goes (ties and the no-bounce rule: the other one); now and then a random one, so that
+                    // a cycle of kicks cannot repeat forever
+                    uint32_t victim = tab[s1].rank > tab[s2].rank ? s1 : s2;
+                    if (((rnd >> 16) & 7u) == 0u) victim = (rnd >> 20) & 1u ? s2 : s1;
                     if (victim == avoid) victim = victim == s1 ? s2 : s1;   // do not bounce straight back
                     std::swap(e, tab[victim]);
                     avoid = victim;
@@ -292,7 +305,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
 // table cache (row f-2)
 // ------------------------------------------------------------------------------------------
 #define TK_CACHE_MAGIC 0x42544B54u /* "TKTB" */
-#define TK_CACHE_VERSION 5u        /* bump whenever a table layout or a hash function changes */
+#define TK_CACHE_VERSION 6u        /* bump whenever a table layout or a hash function changes */
 
 static uint64_t fnv1a64(uint64_t h, const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;

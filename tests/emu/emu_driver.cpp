@@ -153,6 +153,10 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         for (uint64_t e = 0; e < 2 * n_chunks; ++e)
             for (uint64_t w = (mpfx[e] + 63) / 64; w * 64 < mpfx[e + 1]; ++w) wave_first[w] = (uint32_t)e;
         fa.wave_first = wave_first.data();
+        std::vector<uint32_t> wave_first_wide(n_wide / 64 + 2, 0);
+        for (uint64_t e = 2 * n_chunks; e < 4 * n_chunks; ++e)
+            for (uint64_t w = (mpfx[e] - n_narrow + 63) / 64; w * 64 < mpfx[e + 1] - n_narrow; ++w) wave_first_wide[w] = (uint32_t)e;
+        fa.wave_first_wide = wave_first_wide.data();
         // the wave's LDS columns sit between two guard zones: a write outside the kernel's share (8 KB narrow, 16 KB
         // wide) would be silent on the device
         const size_t G = 256;

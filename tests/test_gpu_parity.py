@@ -261,6 +261,50 @@ def test_device_resident_entry_and_full_size_properties(tk, eng_bench, bench_voc
     assert tm["encode_kernel_ms"] > 0 and tm["pipeline_ms"] >= tm["encode_kernel_ms"]
 
 
+def test_full_size_mixed_utf8_properties(tk, eng_bench, bench_vocab):
+    """BASELINE config C3 at FULL size (1 M x 2 KiB mixed UTF-8, 2.05 GB) with inputs resident in HBM: determinism, the
+    bytes of the emitted tokens concatenate back to the input, one BOS / EOS per document, nothing handed back, three
+    samples of 3 000 documents id for id against the oracle, and the GPU batch decode gives the text back."""
+    import torch
+    n_docs = 1_000_000
+    data, offs = corpus.generate("mixed", n_docs, 2048, seed=corpus.BASE_SEED + 1)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    sums = []
+    for _ in range(2):
+        v_ids, v_oo = eng_bench.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, len(data), True, True, stream)
+        ids = torch.as_tensor(v_ids, device="cuda")
+        oo = torch.as_tensor(v_oo, device="cuda")
+        ids_h = ids.cpu().numpy().view(np.uint32)
+        oo_h = oo.cpu().numpy().astype(np.uint64)
+        sums.append(tk_oracle.fnv1a(ids_h))
+    assert sums[0] == sums[1]
+    assert eng_bench.last_stats()["handed_back"] == 0
+    # round trip on the device while the ids are still there
+    ids_keep, oo_keep = ids.clone(), oo.clone()
+    v_b, _ = eng_bench.decode_batch_device(ids_keep.data_ptr(), oo_keep.data_ptr(), n_docs, ids_keep.numel(), tk.SpecialTokenPolicy.Ignore, stream)
+    back = torch.as_tensor(v_b, device="cuda")
+    assert back.numel() == len(data) and bool(torch.equal(back, d_bytes))
+    del back, ids_keep, oo_keep
+    ns = bench_vocab["num_special"]
+    assert int(oo_h[-1]) == len(ids_h) and np.all(np.diff(oo_h.astype(np.int64)) >= 2)
+    tok_len = np.array([len(t) for t in bench_vocab["tokens"]], dtype=np.int64)
+    body = ids_h[ids_h >= ns]
+    assert int(tok_len[body - ns].sum()) == len(data)
+    assert len(ids_h) - len(body) == 2 * n_docs
+    first = oo_h[:-1].astype(np.int64)
+    last = oo_h[1:].astype(np.int64) - 1
+    assert np.all(ids_h[first] == bench_vocab["bos"]) and np.all(ids_h[last] == bench_vocab["eos"])
+    orc = helpers.oracle_for(bench_vocab)
+    for lo in (0, 480_000, 997_000):
+        hi = lo + 3000
+        sub_offs = offs[lo:hi + 1] - offs[lo]
+        eids, _ = orc.encode_batch(data[int(offs[lo]):int(offs[hi])], sub_offs, True, True, threads=8)
+        got = ids_h[int(oo_h[lo]):int(oo_h[hi])]
+        assert tk_oracle.fnv1a(got) == tk_oracle.fnv1a(eids) and len(got) == len(eids)
+
+
 def test_invalid_utf8_without_validation_is_safe(eng_small):
     """Callers that skip validation and pass malformed bytes get unspecified ids but no crash, no hang,
     and the id count stays within the documented bound (bytes + 2 per document)."""

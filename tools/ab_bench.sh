@@ -6,7 +6,7 @@ cp tekken-rs_amd/libtekken_hip.so gpurun_out/lib_keep.so
 for rep in 1 2 3; do
   for v in "$@"; do
     cp $v tekken-rs_amd/libtekken_hip.so
-    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --cpu-passes 0 --decode-steps 0 --host-steps 0 2>/dev/null | python -c "
+    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'rep', $rep, 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'])" || exit 1
   done

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   name=$1; shift
   timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}_${name} -o $tag -- \
-    python3 $root/bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 > $root/gpurun_out/pmc_${tag}_${name}.log 2>&1 || return 1
+    python3 $root/bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > $root/gpurun_out/pmc_${tag}_${name}.log 2>&1 || return 1
   echo "pass $name done"
 }
 run fetch FETCH_SIZE && run write WRITE_SIZE && \

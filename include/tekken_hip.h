@@ -90,6 +90,9 @@ int tk_encode_one(tk_ctx* ctx, const uint8_t* text, uint64_t len, int add_bos, i
                   uint64_t ids_capacity, uint64_t* n_ids);
 /* Calls on this context served by the one-launch path so far (diagnostics / tests). */
 uint64_t tk_small_path_calls(const tk_ctx* ctx);
+/* Documents so far whose long piece (>= 1 KiB, not a vocabulary key) was merged in rounds by a whole workgroup
+ * (csrc/tk_long.hip) instead of step by step by one wave (diagnostics / tests; TK_LONG_MIN overrides the threshold). */
+uint64_t tk_round_path_docs(const tk_ctx* ctx);
 
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference

@@ -108,6 +108,8 @@ def lib():
     L.tk_encode_one.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, ctypes.c_uint64, u64p]
     L.tk_small_path_calls.restype = ctypes.c_uint64
     L.tk_small_path_calls.argtypes = [vp]
+    L.tk_round_path_docs.restype = ctypes.c_uint64
+    L.tk_round_path_docs.argtypes = [vp]
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
@@ -310,6 +312,10 @@ class Engine:
         if rc != TK_OK:
             raise self._err(rc)
         return out[:n.value]
+
+    def round_path_docs(self):
+        """Documents so far whose long piece was merged in rounds by a workgroup (csrc/tk_long.hip)."""
+        return int(lib().tk_round_path_docs(self._h))
 
     def small_path_calls(self):
         """Calls served by the one-launch small-batch path so far."""

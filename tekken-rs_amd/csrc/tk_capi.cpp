@@ -116,6 +116,11 @@ struct tk_ctx {
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
+    DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
+    DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
+    uint32_t long_min = 1024;      // shortest piece (bytes) merged in rounds by a workgroup (TK_LONG_MIN; 0 = never)
+    uint32_t long_force = 0;       // TK_LONG_FORCE (tests): rounds for every long piece, not only the repetitive ones
+    uint64_t n_round_docs = 0;     // documents the round-based kernel took in the last call
     DevBuf f_first, f_tmp, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_info;  // flat path (tk_flat.hip)
     bool use_flat = true;
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
@@ -242,6 +247,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         c->err = "wave primitive self-test failed on this device (mask " + std::to_string(bad) + ")";
         return fail(TK_ERR_RUNTIME);
     }
+    if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
+    if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
         c->pipeline_forced = strcmp(pl, "doc") == 0 ? 2 : strcmp(pl, "flat") == 0 ? 1 : 0;
     *out_ctx = c;
@@ -255,7 +262,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
-                      &c->scratch, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
+                      &c->scratch, &c->long_list, &c->long_jobs, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
@@ -313,9 +320,56 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
     a.n_todo = n_def;
     a.scratch = (uint32_t*)c->scratch.p;
     a.scratch_words_per_wave = words;
+    // documents with a LONG piece that is not a vocabulary key are handed on to the workgroup-per-document kernel
+    // (tk_long.hip: the piece is merged in rounds by 16 waves instead of step by step by one)
+    uint32_t* d_long_count = (uint32_t*)c->counters.p + 9;
+    if (c->long_min) {
+        TK_HIP(c, c->long_list.reserve(((size_t)n_def + 1) * 4));
+        a.long_list = (uint32_t*)c->long_list.p;
+        a.long_count = d_long_count;
+        a.long_min = c->long_min < 65u ? 65u : c->long_min;
+        a.long_force = c->long_force;
+    }
     TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
+    TK_HIP(c, hipMemsetAsync(d_long_count, 0, 4, s));
     TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
     if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] pass2 kernel done\n"); }
+    if (c->long_min) {
+        TK_HIP(c, hipMemcpyAsync(c->h_pin + 9, d_long_count, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        const uint32_t n_long = c->h_pin[9];
+        c->n_round_docs += n_long;
+        if (n_long) {
+            // walk (one wave per document; long pieces become jobs) -> merge the jobs in rounds (one workgroup each) ->
+            // squeeze the holes out.  No host sync in between: the merge grid is persistent and reads the job count itself.
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            const uint64_t fit = budget_words / words >= 4 ? budget_words / words : 4;   // scratch slices the budget allows
+            uint64_t walk_waves = ((n_long < 1024u ? n_long : 1024u) + 3) / 4 * 4;
+            uint64_t blocks = (uint64_t)2 * cus;                                   // two 16-wave blocks fill a CU
+            if (walk_waves > fit) walk_waves = fit / 4 * 4;
+            if (blocks > fit) blocks = fit;
+            TK_HIP(c, c->scratch.reserve((walk_waves > blocks ? walk_waves : blocks) * words * 4));   // (pass 2 is complete: its slices are free)
+            const uint64_t job_cap = maxlen / (a.long_min ? a.long_min : 1) * (uint64_t)n_long + n_long + 16;
+            TK_HIP(c, c->long_jobs.reserve(job_cap * sizeof(TkLongJob)));
+            uint32_t* d_job_count = (uint32_t*)c->counters.p + 10;
+            TkEncodeArgs b = a;
+            b.todo_list = (const uint32_t*)c->long_list.p;
+            b.n_todo = n_long;
+            b.long_list = nullptr;
+            b.long_jobs = (TkLongJob*)c->long_jobs.p;
+            b.long_job_count = d_job_count;
+            b.long_job_cap = (uint32_t)(job_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : job_cap);
+            b.scratch = (uint32_t*)c->scratch.p;
+            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
+            TK_HIP(c, hipMemsetAsync(d_job_count, 0, 4, s));
+            TK_HIP(c, tk_launch_encode_long(b, (uint32_t)walk_waves, 0, s));
+            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counter
+            const uint64_t cblocks = (n_long + 3) / 4 < 4096 ? (n_long + 3) / 4 : 4096;
+            TK_HIP(c, tk_launch_encode_long_merge(b, (uint32_t)blocks, (uint32_t)cblocks, s));
+            if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] round-based kernels done: %u documents\n", n_long); }
+        }
+    }
     return TK_OK;
 }
 
@@ -465,7 +519,8 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
                                           (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id,
-                                          c->host.eos_id, add_bos, add_eos, (uint64_t*)((uint32_t*)c->counters.p + 6), s));
+                                          c->host.eos_id, add_bos, add_eos, (uint64_t*)((uint32_t*)c->counters.p + 6),
+                                          final_pass ? nullptr : (const uint32_t*)c->counters.p + 4, s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
         // counters 4 (handed-back documents) and 6..7 (total ids, left there by the assembly): one copy into pinned memory
         TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 32, hipMemcpyDeviceToHost, s));
@@ -982,6 +1037,7 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
 }
 
 extern "C" uint64_t tk_small_path_calls(const tk_ctx* c) { return c ? c->n_small_calls : 0; }
+extern "C" uint64_t tk_round_path_docs(const tk_ctx* c) { return c ? c->n_round_docs : 0; }
 
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;

@@ -39,6 +39,7 @@
 #define TK_DEAD 0xFFFFFFFFu
 #define TK_NONE 0xFFFFFFFFu
 #define TK_DOC_CHUNK 8u /* documents taken per work-queue fetch */
+#define TK_LONG_MAX 32768u /* longest piece the round-based merge takes (16 waves x 32 steps x 64 parts) */
 
 
 struct TkPolyPow {  // per-lane powers of the two polynomial bases
@@ -288,6 +289,20 @@ TK_DEV uint32_t tk_fold(uint32_t cp) {
     return cp;
 }
 
+// Wave-cooperative fast-forward over a run of ASCII bytes of class `cls`, 64 bytes per step (called by all 64 lanes in
+// convergence; every lane gets the same answer): the first position at or after q whose byte is not ASCII of that class
+// (or n).  The per-byte loops of the matcher below are sequential dependent loads -- 32 KiB of letters took a wave 6 ms.
+TK_DEV uint64_t tk_skip_ascii_run(const uint8_t* b, uint64_t q, uint64_t n, uint32_t cls) {
+    const int lane = wv_lane();
+    for (;;) {
+        const uint64_t p = q + (uint64_t)lane;
+        const uint32_t c = p < n ? (uint32_t)b[p] : 0x80u;
+        const uint64_t stop = wv_ballot(c >= 0x80u || tk_ascii_class(c) != cls);
+        if (stop) return q + (uint64_t)tk_ctz64(stop);
+        q += 64;
+    }
+}
+
 TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t pos, uint64_t n) {
     uint32_t l0, l1, l2, c0, c1, c2;
     uint32_t k0 = tk_class_at(t, b, pos, n, &l0, &c0);
@@ -308,6 +323,8 @@ TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t p
             uint64_t p = attempt == 0 ? pos + l0 : pos;
             uint64_t q = p;
             while (q < n) {
+                q = tk_skip_ascii_run(b, q, n, TK_CLS_L);           // ASCII letters 64 at a time, then char by char
+                if (q >= n) break;
                 uint32_t l, c;
                 if (tk_class_at(t, b, q, n, &l, &c) != TK_CLS_L) break;
                 q += l;
@@ -328,6 +345,8 @@ TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t p
         uint64_t p = attempt == 0 ? pos + 1 : pos;
         uint64_t q = p;
         while (q < n) {
+            q = tk_skip_ascii_run(b, q, n, TK_CLS_O);
+            if (q >= n) break;
             uint32_t l, c;
             if (tk_class_at(t, b, q, n, &l, &c) != TK_CLS_O) break;
             q += l;
@@ -340,6 +359,18 @@ TK_DEV uint64_t tk_match_end(const TkTablesView& t, const uint8_t* b, uint64_t p
     // alts 5-7 over the maximal white-space run
     uint64_t e = pos, after_last_nl = 0, last_char = pos;
     bool has_nl = false;
+    {
+        // whole blocks of 64 ASCII white-space bytes at a time (the last CR / LF of a block from a ballot)
+        const int lane = wv_lane();
+        while (e + 64 <= n) {
+            const uint32_t c = b[e + (uint64_t)lane];
+            if (wv_ballot(c >= 0x80u || tk_ascii_class(c) != TK_CLS_S)) break;
+            const uint64_t NL = wv_ballot(c == '\r' || c == '\n');
+            if (NL) { has_nl = true; after_last_nl = e + (uint64_t)tk_msb64(NL) + 1; }
+            last_char = e + 63;
+            e += 64;
+        }
+    }
     while (e < n) {
         uint32_t l, c;
         if (tk_class_at(t, b, e, n, &l, &c) != TK_CLS_S) break;
@@ -457,8 +488,8 @@ TK_DEV uint64_t tk_match_end2(const TkTablesView& t, const uint8_t* b, uint64_t 
 // pass 2, one piece [w0, e) of any length: whole-piece lookup (wave-wide polynomial hash for
 // pieces of >= 9 bytes), and on a miss the wave-cooperative merge over scratch memory.
 // ------------------------------------------------------------------------------------------
-TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e,
-                          uint32_t* out, uint32_t& cursor, uint32_t* scratch) {
+// whole-piece lookup of the piece [w0, e): its rank or TK_RANK_MAX (wave-uniform)
+TK_DEV uint32_t tk_piece_lookup(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e) {
     const TkTablesView& t = a.t;
     const uint64_t n = e - w0;
     uint32_t r = TK_RANK_MAX;
@@ -482,12 +513,53 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         }
         r = tk_probe_long(t, h1, h2, (uint32_t)n, a.bytes + w0);
     }
-    r = wv_first(r);
+    return wv_first(r);
+}
+
+TK_DEV void tk_piece_merge_coop(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e, uint32_t* out, uint32_t& cursor, uint32_t* scratch,
+                                bool light = false);
+
+// Is the long piece [w0, e) REPETITIVE -- few distinct adjacent byte pairs among its first 512 bytes (runs of white space,
+// of one symbol, of a short period)?  Such a piece merges many pairs per rank: the round-based workgroup merge
+// (tk_long.hip) is up to 15x faster on it than one merge per step; on a piece with many distinct pairs (random letters: a
+// dozen merges per rank) a round costs more than the dozen steps, and the piece stays with the single-wave merge
+// (measured).  A pure function of the bytes: every kernel that asks gets the same answer.  Wave-uniform.
+TK_DEV bool tk_piece_repetitive(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e) {
+    uint64_t seen = 0ull;                                        // pairs hashed into 64 buckets
+    for (uint32_t k0 = 0; k0 < 512u; k0 += 64u) {
+        const uint64_t p = w0 + k0 + (uint64_t)lane;
+        if (p + 1 < e) {
+            const uint32_t h = ((uint32_t)a.bytes[p] * 31u + (uint32_t)a.bytes[p + 1] * 7u) & 63u;
+            seen |= 1ull << h;
+        }
+    }
+    // OR over the lanes: one ballot per bucket would be 64 ballots; fold with shuffles instead (6 steps, two words)
+    uint32_t lo = (uint32_t)seen, hi = (uint32_t)(seen >> 32);
+    for (int d = 1; d < 64; d <<= 1) {
+        lo |= wv_shfl(lo, lane ^ d);
+        hi |= wv_shfl(hi, lane ^ d);
+    }
+    return (uint32_t)__builtin_popcount(wv_first(lo)) + (uint32_t)__builtin_popcount(wv_first(hi)) <= 20u;
+}
+
+TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e,
+                          uint32_t* out, uint32_t& cursor, uint32_t* scratch) {
+    const uint32_t r = tk_piece_lookup(a, pw, lane, w0, e);
     if (r != TK_RANK_MAX) {
-        if (lane == 0) out[cursor] = r + t.num_special;
+        if (lane == 0) out[cursor] = r + a.t.num_special;
         cursor += 1;
         return;
     }
+    tk_piece_merge_coop(a, lane, w0, e, out, cursor, scratch);
+}
+
+// the wave-cooperative merge of a piece that is not a vocabulary key (one merge per step, tiktoken's order)
+// light (a compile-time constant at every call site): only the plain form with the block minima in scratch -- fewer registers,
+// for the workgroup-per-document kernel, whose 1024-thread blocks leave a wave 128 of them
+TK_DEV void tk_piece_merge_coop(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e, uint32_t* out, uint32_t& cursor, uint32_t* scratch,
+                                bool light) {
+    const TkTablesView& t = a.t;
+    const uint64_t n = e - w0;
 
     // ---- wave-cooperative merge over scratch: node[nn] = {tok, prk, nxt, prv} (16 B) | bmin[nb] (u64) ----
     // prk = rank of the pair (this part, next part); bmin[b] = min over the 64 nodes of block b of
@@ -511,7 +583,7 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
         node[i] = v;
     }
     wv_sync();
-    if (nb <= 512u) {
+    if (!light && nb <= 512u) {
         // ---- up to 32 KiB: the block minima live in REGISTERS (lane l holds blocks l, l + 64, ...: 8 slots), every node
         // carries the token of its successor (tokn), and the rows of the (at most three) blocks whose minimum changes are
         // requested together with nodes j and p.  Dependent round trips per merge: node i | nodes j, p, tokn[j], rows |
@@ -1024,7 +1096,21 @@ TK_DEV void tk_encode_doc_seq(const TkEncodeArgs& a, uint64_t d, int lane, const
     uint64_t w0 = s0;
     while (w0 < s1) {
         const uint64_t e = wv_first64(a.pattern ? tk_match_end2(t, a.bytes, w0, s1) : tk_match_end(t, a.bytes, w0, s1));
-        tk_piece_coop(a, pw, lane, w0, e, out, cursor, scratch);
+        const uint32_t r = tk_piece_lookup(a, pw, lane, w0, e);
+        if (r != TK_RANK_MAX) {
+            if (lane == 0) out[cursor] = r + t.num_special;
+            cursor += 1;
+        } else if (a.long_list && e - w0 >= (uint64_t)a.long_min && e - w0 <= TK_LONG_MAX && (a.long_force || tk_piece_repetitive(a, lane, w0, e))) {
+            // a LONG repetitive piece that is not a vocabulary key: thousands of dependent merges for one wave, many of them
+            // of the same rank.  The document goes to tk_long.hip, which merges such a piece in rounds by a workgroup
+            if (lane == 0) {
+                a.counts[d] = 0;
+                a.long_list[wv_atomic_add(a.long_count, 1u)] = (uint32_t)d;
+            }
+            return;
+        } else {
+            tk_piece_merge_coop(a, lane, w0, e, out, cursor, scratch);
+        }
         w0 = e;
     }
     if (a.add_eos) {

@@ -6,6 +6,8 @@
 #include "tk_hash.h"
 #include "tk_tables.h"
 
+struct TkLongJob { uint32_t doc, off, len, pad; };   // a long piece that is not a vocabulary key: bytes [off, off + len) of document doc
+
 struct TkEncodeArgs {
     const uint8_t* bytes;       // packed text of all documents
     const uint64_t* doc_offs;   // [n_docs + 1]
@@ -19,6 +21,13 @@ struct TkEncodeArgs {
     uint32_t n_todo;
     uint8_t* dbg_starts;        // optional: per-byte piece-start flags (tk_split_batch)
     volatile uint32_t* dbg_mark; // optional: progress marks of the long-piece merge (debug builds of the host)
+    uint32_t* long_list;        // pass 2: documents with a long piece that misses the vocabulary, handed on to tk_long.hip (NULL: merged here)
+    uint32_t* long_count;
+    uint32_t long_min;          // shortest piece (bytes) that counts as long
+    uint32_t long_force;        // tests: every long piece takes the round-based merge, repetitive or not
+    TkLongJob* long_jobs;       // tk_long.hip: the long pieces of the documents of the long list
+    uint32_t* long_job_count;
+    uint32_t long_job_cap;
     uint32_t* scratch;          // pass 2: per-wave scratch for the cooperative merge
     uint64_t scratch_words_per_wave;
     int add_bos, add_eos;

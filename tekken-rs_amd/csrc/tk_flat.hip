@@ -243,6 +243,8 @@ struct TkFlatAssembleArgs {
     uint32_t bos_id, eos_id;
     int add_bos, add_eos;
     uint64_t* total_out;      // receives out_offs[n_docs] (the host reads it with the other counters)
+    const uint32_t* skip_if;  // optimistic first pass: nothing is copied when *skip_if != 0 (documents were handed back: the host
+                              // runs the per-document kernels and assembles again); NULL for the final pass
 };
 
 // generic copy of one document (any number of chunks / slots, or a handed-back document)
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
     if (wave == 0 && lane == 0) *a.total_out = a.out_offs[a.n_docs];
+    if (a.skip_if && *a.skip_if != 0u) return;               // (grid-uniform)
     for (uint64_t d0 = wave * 64; d0 < a.n_docs; d0 += n_waves * 64) {
         const uint64_t dm = d0 + (uint64_t)lane;
         TkFlatDocInfo mine;
@@ -448,10 +451,11 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
 
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
-                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, hipStream_t s) {
+                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, const uint32_t* skip_if, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
     TkFlatAssembleArgs a;
     a.total_out = total_out;
+    a.skip_if = skip_if;
     a.n_docs = n_docs; a.info = (const TkFlatDocInfo*)doc_info; a.kcount = kcount; a.out_offs = out_offs;
     a.tmp = tmp; a.staging = staging; a.out_ids = out_ids;
     a.bos_id = bos_id; a.eos_id = eos_id; a.add_bos = add_bos; a.add_eos = add_eos;

@@ -20,6 +20,12 @@ hipError_t tk_launch_encode(const TkEncodeArgs& args, int mode, uint32_t n_waves
 #define TK_SMALL_THREADS 1024
 hipError_t tk_launch_small(const TkEncodeArgs& args, uint32_t* out_ids, uint64_t* out_offs, uint32_t* status, hipStream_t s);
 
+// Workgroup-per-document pass over args.todo_list (documents with a long piece that is not a vocabulary key, handed on by
+// pass 2): the long piece is merged in rounds by 16 waves (tk_long.hip).  Every block owns a scratch slice of
+// args.scratch_words_per_wave words.
+hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves, uint32_t n_merge_blocks, hipStream_t s);
+hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s);
+
 // counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
 // ceil(n/2048)+1 u64.  offs[n] (= total) is also what the host reads back.
 hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s);
@@ -43,7 +49,7 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
                                  uint32_t extra, uint32_t* counts, void* doc_info, int final_pass, uint32_t* n_flagged, hipStream_t s);
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
-                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, hipStream_t s);
+                                   uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, const uint32_t* skip_if, hipStream_t s);
 hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
 
 hipError_t tk_launch_iota(uint32_t* out, uint64_t n, hipStream_t s);   // out[i] = i

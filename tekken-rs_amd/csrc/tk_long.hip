@@ -1,0 +1,400 @@
+// tk_long.hip -- documents with a LONG piece that is not a vocabulary key: one WORKGROUP per document, the long piece
+// merged in ROUNDS.
+//
+// The byte-pair merge (tiktoken's _byte_pair_merge behind CoreBPE::encode, reference src/tekkenizer.rs:384-386; SURVEY
+// App. A.2) is sequential: merge the leftmost pair of minimum rank, re-probe its two neighbours, repeat.  A 32 KiB run of
+// letters is one piece with ~10^4 such steps -- one wave needs ~1.1 us per step (tk_piece_merge_coop), and that single
+// chain was the whole tail of the Zipf shape (BASELINE configs[4]).  All occurrences of the current minimum rank r* can
+// be merged in one parallel sweep (a ROUND) as long as the result stays what the sequential order gives
+// (tools/batched_merge_model.py is the executable statement, checked against the sequential algorithm on adversarial
+// vocabularies):
+//   * candidates = positions whose pair has rank r*; inside a run of CONSECUTIVE candidates only the even offsets merge;
+//   * every merge is probed as the sequential algorithm would see it (left neighbour already merged if the previous
+//     occurrence ends right before it, right neighbour not yet merged); if a created pair ranks BELOW r* the round is cut
+//     after that occurrence -- the sequential algorithm would turn to the new pair first;
+//   * the parts are compacted, the probed ranks become the new pair ranks, the minimum of the new ranks is the next r*.
+// A random-letter piece of 32 KiB takes under a thousand rounds.
+//
+// Layout: the parts (token, rank of the pair with the successor) live in two u32 arrays in global scratch (L2-resident,
+// coalesced); wave w owns a contiguous range, lane l of step s the part w * per + 64 s + l, and holds its range in
+// registers across the round (read once, written once).  Which parts merge is a 64-bit mask per step, derived from the
+// candidate ballot with the carry-ripple trick (runs that start at an even / odd position); the run that crosses a wave
+// boundary is settled with one exchange through LDS.  Six workgroup barriers per round.
+//
+// How the documents get here and back: the three kernels at the end of this file.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tk_kernels.h"
+#include "tk_wave_hip.h"
+#include "tk_encode_impl.h"
+
+#define TKL_THREADS 1024
+#define TKL_WAVES 16
+#define TKL_MAXSTEPS 32                      /* 16 waves x 32 steps x 64 lanes = TK_LONG_MAX parts */
+#define TKL_SELWORDS (TKL_WAVES * TKL_MAXSTEPS)
+
+struct TklShared {
+    uint64_t sel[TKL_SELWORDS + 2];          // [1 + g]: parts of step g (64 consecutive parts) that merge with their successor
+    uint32_t wmin[TKL_WAVES];                // per wave: minimum pair rank of the parts it wrote
+    uint32_t lead[TKL_WAVES];                // per wave: length of the candidate run that starts at its first part
+    uint32_t full[TKL_WAVES];                // per wave: its whole range is one candidate run
+    uint32_t tail_in[TKL_WAVES];             // per wave: its last part is a candidate
+    uint32_t tail_par[TKL_WAVES];            // ... and the length of the run ending there is odd (fresh start assumed)
+    uint32_t wunder[TKL_WAVES];              // per wave: leftmost occurrence that creates a pair below r*
+    uint32_t wcnt[TKL_WAVES];                // per wave: parts that merge
+    uint32_t doc;                            // the job ticket, thread 0 -> everybody
+    uint16_t occ[TKL_WAVES][64 * TKL_MAXSTEPS / 2 + 64];   // per wave: its occurrences (part index relative to the wave's range), ascending
+};
+
+__device__ __forceinline__ uint32_t tkl_wave_min(uint32_t v) { return wv_min_u32(v); }
+
+// parts of a 64-bit candidate mask that sit at an EVEN offset of their run of consecutive candidates.  in_run: the run
+// continues from the part before bit 0, par = parity of its length so far.
+__device__ __forceinline__ uint64_t tkl_even_offsets(uint64_t C, uint32_t in_run, uint32_t par) {
+    const uint64_t E = 0x5555555555555555ull;
+    uint64_t S = C & ~(C << 1);                       // run starts
+    uint64_t seven, sodd;
+    if (in_run && (C & 1ull)) {
+        S &= ~1ull;                                   // bit 0 continues a run: its virtual start has the parity of `par`
+        seven = (S & E) | (par ? 0ull : 1ull);
+        sodd = (S & ~E) | (par ? 1ull : 0ull);
+    } else {
+        seven = S & E;
+        sodd = S & ~E;
+    }
+    (void)sodd;
+    const uint64_t reven = ((C + seven) ^ C) & C;     // the runs that start at an even position (carry ripple)
+    const uint64_t rodd = C & ~reven;
+    return (reven & E) | (rodd & ~E);
+}
+
+// The round-based merge of the piece bytes[0 .. n), 64 < n <= TK_LONG_MAX, by all 16 waves.  Final ids (shifted) go to
+// out[0 ..); returns their number (block-uniform).  scratch: 4 n words (tok | rk | left ranks | right ranks).
+__device__ __forceinline__ uint32_t tkl_block_merge(const TkTablesView& t, const uint8_t* bytes, uint32_t n0, uint32_t* scratch, uint32_t* out,
+                                    TklShared& L) {
+    const int lane = wv_lane();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* Atok = scratch;
+    uint32_t* Ark = scratch + n0;
+    uint32_t* Blr = scratch + 2 * (size_t)n0;
+    uint32_t* Brr = scratch + 3 * (size_t)n0;
+    uint32_t n = n0;
+
+    // ---- start: one part per byte, pair ranks from PAIR2 ----
+    {
+        uint32_t m = TK_RANK_MAX;
+        for (uint32_t i = threadIdx.x; i < n; i += TKL_THREADS) {
+            const uint32_t b0 = bytes[i];
+            const uint32_t r = (i + 1u < n) ? t.pair2[b0 | ((uint32_t)bytes[i + 1u] << 8)] : TK_RANK_MAX;
+            Atok[i] = b0;
+            Ark[i] = r;
+            m = r < m ? r : m;
+        }
+        m = tkl_wave_min(m);
+        if (lane == 0) L.wmin[wv] = m;
+        if (threadIdx.x < 2) L.sel[threadIdx.x ? TKL_SELWORDS + 1 : 0] = 0ull;
+    }
+    __syncthreads();
+
+    for (uint32_t round = 0; round <= n0; ++round) {              // (every round merges at least one pair: at most n0 - 1 rounds)
+        // r* = the minimum over what every wave wrote last
+        uint32_t rstar = lane < TKL_WAVES ? L.wmin[lane] : TK_RANK_MAX;
+        rstar = tkl_wave_min(rstar);
+        if (rstar == TK_RANK_MAX) break;                          // block-uniform
+        const uint32_t per = ((n + TKL_THREADS - 1u) / TKL_THREADS) * 64u;   // parts per wave
+        const uint32_t steps = per / 64u;                          // <= TKL_MAXSTEPS
+        const uint32_t base = wv * per;
+        const uint32_t g0 = wv * steps;                            // index of the wave's first step among all steps
+
+        // ---- R0: the wave's range into registers ----
+        uint32_t tok[TKL_MAXSTEPS], rk[TKL_MAXSTEPS];
+#pragma unroll
+        for (int s = 0; s < TKL_MAXSTEPS; ++s) {
+            tok[s] = 0u; rk[s] = TK_RANK_MAX;
+            if ((uint32_t)s < steps) {
+                const uint32_t i = base + 64u * (uint32_t)s + (uint32_t)lane;
+                if (i < n) { tok[s] = Atok[i]; rk[s] = Ark[i]; }
+            }
+        }
+
+        // ---- R2: candidates, even offsets of their runs (fresh start at the wave's first part) ----
+        {
+            uint32_t in_run = 0, par = 0, lead = 0, lead_open = 1, full = 1;
+#pragma unroll
+            for (int s = 0; s < TKL_MAXSTEPS; ++s) {
+                if ((uint32_t)s < steps) {
+                    const uint64_t C = wv_ballot(rk[s] == rstar);
+                    const uint64_t sel = tkl_even_offsets(C, in_run, par);
+                    if (lane == 0) L.sel[1 + g0 + s] = sel;
+                    if (lead_open) {
+                        if (C == ~0ull) lead += 64u;
+                        else { lead += (uint32_t)tk_ctz64(~C); lead_open = 0; }
+                    }
+                    if (C != ~0ull) full = 0;
+                    in_run = (uint32_t)(C >> 63);
+                    par = in_run ? (uint32_t)(sel >> 63) : 0u;     // last part at an even offset <=> odd length so far
+                }
+            }
+            if (lane == 0) { L.lead[wv] = lead; L.full[wv] = full; L.tail_in[wv] = in_run; L.tail_par[wv] = par; }
+            if (wv == 0 && lane == 0) L.sel[1 + TKL_WAVES * steps] = 0ull;   // the word behind the last step
+        }
+        __syncthreads();
+        {
+            // the run that reaches this wave from the left: walk the waves before it (per is even: a full wave keeps the parity)
+            uint32_t cin = 0, cpar = 0;
+            for (uint32_t v = 0; v < wv; ++v) {
+                if (L.full[v]) { if (!cin) { cin = 1; cpar = 0; } }
+                else { cin = L.tail_in[v]; cpar = L.tail_par[v]; }
+            }
+            const uint32_t lead = L.lead[wv];
+            if (cin && cpar && lead) {
+                // an odd number of candidates before the wave's first part: inside its leading run the OTHER offsets merge
+#pragma unroll
+                for (int s = 0; s < TKL_MAXSTEPS; ++s) {
+                    if ((uint32_t)s < steps && 64u * (uint32_t)s < lead && lane == 0) {
+                        const uint32_t k = lead - 64u * (uint32_t)s;
+                        L.sel[1 + g0 + s] ^= tk_lowmask(k >= 64u ? 64 : (int)k);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- R3: the wave's occurrences as a list (ascending), then ONE LANE PER OCCURRENCE: the two pairs it creates, probed as
+        // the sequential order would see them.  (A loop over the steps with the probes inside pays the chain neighbour loads
+        // -> probes -> stores once per step that has an occurrence; the list pays it once per 64 occurrences.)
+        uint16_t* occ = L.occ[wv];
+        uint32_t cntw = 0;
+#pragma unroll 1
+        for (uint32_t s = 0; s < steps; ++s) {
+            const uint64_t sel = L.sel[1 + g0 + s];
+            if (sel) {                                             // wave-uniform
+                if (tk_bit(sel, lane)) occ[cntw + (uint32_t)tk_popc64(sel & tk_lowmask(lane))] = (uint16_t)(64u * s + (uint32_t)lane);
+                cntw += (uint32_t)tk_popc64(sel);
+            }
+        }
+        wv_lds_sync();
+        uint32_t umin = 0xFFFFFFFFu;
+        uint32_t lr0 = TK_RANK_MAX, rr0 = TK_RANK_MAX;               // the first batch keeps its results in registers
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < cntw) {
+                const uint32_t i = base + (uint32_t)occ[k];
+                uint32_t lr = TK_RANK_MAX, rr = TK_RANK_MAX;
+                uint32_t tl = 0, tr = 0;
+                const bool hasl = i > 0u, hasr = i + 2u < n;
+                if (hasl) {
+                    // the part before: already merged if the occurrence two parts back merges
+                    const bool lm = i >= 2u && tk_bit(L.sel[1 + ((i - 2u) >> 6)], (int)((i - 2u) & 63u));
+                    tl = lm ? rstar : Atok[i - 1u];
+                }
+                if (hasr) tr = Atok[i + 2u];
+                tk_probe_pair_x2(t, hasl ? tl : 0u, rstar, rstar, hasr ? tr : 0u, lr, rr);
+                if (!hasl) lr = TK_RANK_MAX;
+                if (!hasr) rr = TK_RANK_MAX;
+                if (k0 == 0u) { lr0 = lr; rr0 = rr; }
+                else { Blr[i] = lr; Brr[i] = rr; }
+                if (lr < rstar || rr < rstar) umin = i < umin ? i : umin;
+            }
+        }
+        umin = tkl_wave_min(umin);
+        if (lane == 0) L.wunder[wv] = umin;
+        __syncthreads();
+        uint32_t ustar = lane < TKL_WAVES ? L.wunder[lane] : 0xFFFFFFFFu;
+        ustar = tkl_wave_min(ustar);
+
+        // ---- R4: cut the round behind the first occurrence that creates a pair below r* (the lists are ascending: a prefix
+        // of every list stays); count ----
+        if (ustar != 0xFFFFFFFFu) {                                // block-uniform, rare
+            uint32_t kept = 0;
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                kept += (uint32_t)tk_popc64(wv_ballot(k < cntw && base + (uint32_t)occ[k < cntw ? k : 0u] <= ustar));
+            }
+            cntw = kept;
+#pragma unroll 1
+            for (uint32_t s = 0; s < steps; ++s) {
+                const uint32_t first = base + 64u * s;
+                const uint64_t keep = ustar < first ? 0ull : tk_lowmask(ustar - first >= 63u ? 64 : (int)(ustar - first + 1u));
+                if (lane == 0) L.sel[1 + g0 + s] &= keep;
+            }
+        }
+        if (lane == 0) L.wcnt[wv] = cntw;
+        __syncthreads();   // every old part and neighbour has been read: the arrays may be rewritten
+        uint32_t before = 0, total = 0;
+        for (uint32_t v = 0; v < TKL_WAVES; ++v) {
+            const uint32_t c = L.wcnt[v];
+            if (v < wv) before += c;
+            total += c;
+        }
+
+        // ---- R5: commit + compact (new index = old index - occurrences before it), minimum of the new ranks.  Every slot of
+        // the rank array is written exactly once: an unchanged pair by its part (a), the pair behind an occurrence and the
+        // pair in front of it by the occurrence (b) -- the pair between two back-to-back occurrences by the second one. ----
+        uint32_t mnew = TK_RANK_MAX;
+        {
+            uint32_t run = before;
+#pragma unroll
+            for (int s = 0; s < TKL_MAXSTEPS; ++s) {
+                if ((uint32_t)s < steps) {
+                    const uint32_t g = g0 + (uint32_t)s;
+                    const uint64_t sel = L.sel[1 + g], prev = L.sel[g], next = L.sel[2 + g];
+                    const uint64_t dead = (sel << 1) | (prev >> 63);           // the part after an occurrence is consumed
+                    const uint64_t sel1 = (sel >> 1) | (next << 63);           // an occurrence right after me
+                    const uint32_t i = base + 64u * (uint32_t)s + (uint32_t)lane;
+                    if (i < n && !tk_bit(dead, lane)) {
+                        const uint32_t ni = i - (run + (uint32_t)tk_popc64(sel & tk_lowmask(lane)));
+                        const bool me = tk_bit(sel, lane);
+                        Atok[ni] = me ? rstar : tok[s];
+                        if (!me && !tk_bit(sel1, lane)) {
+                            Ark[ni] = rk[s];
+                            mnew = rk[s] < mnew ? rk[s] : mnew;
+                        }
+                    }
+                    run += (uint32_t)tk_popc64(sel);
+                }
+            }
+        }
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < cntw) {
+                const uint32_t i = base + (uint32_t)occ[k];
+                uint32_t lr = lr0, rr = rr0;
+                if (k0 != 0u) { lr = Blr[i]; rr = Brr[i]; }
+                const uint32_t ni = i - (before + k);
+                const bool next2 = i + 2u < n && tk_bit(L.sel[1 + ((i + 2u) >> 6)], (int)((i + 2u) & 63u));
+                if (!next2) { Ark[ni] = rr; mnew = rr < mnew ? rr : mnew; }
+                if (i > 0u) { Ark[ni - 1u] = lr; mnew = lr < mnew ? lr : mnew; }
+            }
+        }
+        mnew = tkl_wave_min(mnew);
+        if (lane == 0) L.wmin[wv] = mnew;
+        n -= total;
+        __syncthreads();   // the new arrays and minima are in place
+        if (total == 0u) break;                                    // (cannot happen: the leftmost candidate always merges)
+    }
+
+    for (uint32_t i = threadIdx.x; i < n; i += TKL_THREADS) out[i] = Atok[i] + t.num_special;
+    __syncthreads();   // the scratch is wave 0's again (the single-wave merge of the next ordinary piece uses it)
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The documents of the long list take three launches:
+//   tk_long_walk_kernel     one wave per document walks it piece by piece (sequential matcher, whole-piece lookup, the
+//                           single-wave merge for ordinary pieces) and writes the ids of the piece at byte offset p to
+//                           staging slot p (a piece of L bytes has at most L ids; the slots it does not use become
+//                           holes); a long piece that is not a vocabulary key becomes a JOB instead;
+//   tk_long_merge_kernel    one workgroup per job: the round-based merge above, ids (+ holes) into the piece's slots;
+//   tk_long_compact_kernel  one wave per document squeezes the holes out, appends EOS and writes the id count.
+// (One fused kernel -- wave 0 walking, all waves joining for a long piece -- was the first form: the walker's 136 registers
+// under the 128 a 1024-thread block leaves a wave spilled 237 of them and dragged the round loop's arrays into scratch.)
+// ------------------------------------------------------------------------------------------------------------------
+#define TKL_HOLE 0xFFFFFFFFu
+
+__global__ __launch_bounds__(256) void tk_long_walk_kernel(TkEncodeArgs a) {
+    const int lane = wv_lane();
+    const TkTablesView& t = a.t;
+    const TkPolyPow pw = tk_poly_pow(t, lane);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t* scratch = a.scratch + wave_id * a.scratch_words_per_wave;
+    for (;;) {
+        const uint32_t ticket = wv_first(wv_atomic_add_all(a.work_counter, 1u));   // (all lanes take part: see tk_encode_wave)
+        const uint32_t q = ticket / 64u;
+        if (q >= a.n_todo) break;
+        const uint64_t d = (uint64_t)wv_first(a.todo_list[q]);
+        const uint64_t s0 = wv_first64(a.doc_offs[d]), s1 = wv_first64(a.doc_offs[d + 1]);
+        uint32_t* out = a.staging + s0 + 2 * d;
+        const uint32_t base = a.add_bos ? 1u : 0u;
+        if (a.add_bos && lane == 0) out[0] = t.bos_id;
+        uint64_t w0 = s0;
+        while (w0 < s1) {
+            const uint64_t e = wv_first64(a.pattern ? tk_match_end2(t, a.bytes, w0, s1) : tk_match_end(t, a.bytes, w0, s1));
+            const uint32_t len = (uint32_t)(e - w0);
+            uint32_t* dst = out + base + (w0 - s0);
+            const uint32_t r = tk_piece_lookup(a, pw, lane, w0, e);
+            uint32_t cur = 0;
+            if (r != TK_RANK_MAX) {
+                if (lane == 0) dst[0] = r + t.num_special;
+                cur = 1;
+            } else if (len >= a.long_min && len <= TK_LONG_MAX && (a.long_force || tk_piece_repetitive(a, lane, w0, e))) {
+                if (lane == 0) {
+                    const uint32_t slot = wv_atomic_add(a.long_job_count, 1u);
+                    if (slot < a.long_job_cap) {
+                        TkLongJob j;
+                        j.doc = (uint32_t)d; j.off = (uint32_t)(w0 - s0); j.len = len; j.pad = 0u;
+                        a.long_jobs[slot] = j;
+                    }
+                }
+                cur = len;                                         // (its slots are written by tk_long_merge_kernel)
+            } else {
+                tk_piece_merge_coop(a, lane, w0, e, dst, cur, scratch);
+            }
+            for (uint32_t k = cur + (uint32_t)lane; k < len; k += 64u) dst[k] = TKL_HOLE;
+            w0 = e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TKL_THREADS) void tk_long_merge_kernel(TkEncodeArgs a) {
+    __shared__ TklShared L;
+    uint32_t* scratch = a.scratch + (size_t)blockIdx.x * a.scratch_words_per_wave;
+    const uint32_t n_jobs = *a.long_job_count < a.long_job_cap ? *a.long_job_count : a.long_job_cap;
+    const uint32_t base = a.add_bos ? 1u : 0u;
+    for (;;) {
+        if (threadIdx.x == 0) L.doc = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        const uint32_t q = L.doc;
+        __syncthreads();                                           // everybody has the ticket before it is overwritten
+        if (q >= n_jobs) break;                                    // block-uniform
+        const TkLongJob j = a.long_jobs[q];
+        const uint64_t s0 = a.doc_offs[j.doc];
+        uint32_t* out = a.staging + s0 + 2ull * j.doc + base + j.off;
+        const uint32_t n = tkl_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);
+        for (uint32_t i = n + threadIdx.x; i < j.len; i += TKL_THREADS) out[i] = TKL_HOLE;
+    }
+}
+
+__global__ __launch_bounds__(256) void tk_long_compact_kernel(TkEncodeArgs a) {
+    const int lane = wv_lane();
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t q = wave; q < a.n_todo; q += n_waves) {
+        const uint64_t d = a.todo_list[q];
+        const uint64_t s0 = a.doc_offs[d], s1 = a.doc_offs[d + 1];
+        uint32_t* out = a.staging + s0 + 2 * d + (a.add_bos ? 1u : 0u);
+        const uint32_t len = (uint32_t)(s1 - s0);
+        uint32_t wr = 0;
+        for (uint32_t k0 = 0; k0 < len; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            const uint32_t v = k < len ? out[k] : TKL_HOLE;
+            const uint64_t keep = wv_ballot(v != TKL_HOLE);
+            // (the slots written are at or below the ones just read; the ballot orders the loads before the stores)
+            if (v != TKL_HOLE) out[wr + (uint32_t)tk_popc64(keep & tk_lowmask(lane))] = v;
+            wr += (uint32_t)tk_popc64(keep);
+            wv_sync();
+        }
+        if (lane == 0) {
+            if (a.add_eos) out[wr] = a.t.eos_id;
+            a.counts[d] = wr + (a.add_bos ? 1u : 0u) + (a.add_eos ? 1u : 0u);
+        }
+    }
+}
+
+// the long list (documents pass 2 handed on): walk, merge the jobs, compact.  scratch: args.scratch_words_per_wave words
+// per walking wave / per merging workgroup.
+hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves, uint32_t n_merge_blocks, hipStream_t s) {
+    if (args.n_todo == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_long_walk_kernel, dim3((n_walk_waves + 3) / 4), dim3(256), 0, s, args);
+    return hipGetLastError();
+}
+hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s) {
+    if (args.n_todo == 0) return hipSuccess;
+    hipLaunchKernelGGL(tk_long_merge_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
+    hipLaunchKernelGGL(tk_long_compact_kernel, dim3(n_compact_blocks), dim3(256), 0, s, args);
+    return hipGetLastError();
+}

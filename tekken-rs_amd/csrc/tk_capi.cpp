@@ -364,7 +364,8 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
             TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
             TK_HIP(c, hipMemsetAsync(d_job_count, 0, 4, s));
             TK_HIP(c, tk_launch_encode_long(b, (uint32_t)walk_waves, 0, s));
-            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counter
+            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counters (one per merge kernel)
+            TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 11, 0, 4, s));
             const uint64_t cblocks = (n_long + 3) / 4 < 4096 ? (n_long + 3) / 4 : 4096;
             TK_HIP(c, tk_launch_encode_long_merge(b, (uint32_t)blocks, (uint32_t)cblocks, s));
             if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] round-based kernels done: %u documents\n", n_long); }

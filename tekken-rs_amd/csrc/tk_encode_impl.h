@@ -488,6 +488,20 @@ TK_DEV uint64_t tk_match_end2(const TkTablesView& t, const uint8_t* b, uint64_t 
 // pass 2, one piece [w0, e) of any length: whole-piece lookup (wave-wide polynomial hash for
 // pieces of >= 9 bytes), and on a miss the wave-cooperative merge over scratch memory.
 // ------------------------------------------------------------------------------------------
+// Which merge a piece [w0, e) that is not a vocabulary key takes (wave-uniform; a pure function of the bytes and the
+// thresholds, so every kernel that asks gets the same answer): 0 = one merge per step by this wave; 1 = the compacting
+// rounds of tk_long.hip (repetitive pieces of >= long_min bytes: thousands of occurrences per rank -- 15x); 2 = the lazy
+// rounds (pieces with many distinct pairs of >= 4 long_min bytes: 2.3x at 32 KiB, break-even near 4 KiB; below that the
+// rounds' fixed cost of ~5 us loses against a dozen steps of 1.1 us).  long_force (tests): 1 / 2 = every long piece there.
+TK_DEV bool tk_piece_repetitive(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e);
+TK_DEV uint32_t tk_piece_is_long(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e) {
+    const uint64_t len = e - w0;
+    if (len < (uint64_t)a.long_min || len > TK_LONG_MAX) return 0u;
+    if (a.long_force) return a.long_force == 1u ? 1u : 2u;
+    if (tk_piece_repetitive(a, lane, w0, e)) return 1u;
+    return len >= 4ull * a.long_min ? 2u : 0u;
+}
+
 // whole-piece lookup of the piece [w0, e): its rank or TK_RANK_MAX (wave-uniform)
 TK_DEV uint32_t tk_piece_lookup(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, uint64_t w0, uint64_t e) {
     const TkTablesView& t = a.t;
@@ -1100,9 +1114,9 @@ TK_DEV void tk_encode_doc_seq(const TkEncodeArgs& a, uint64_t d, int lane, const
         if (r != TK_RANK_MAX) {
             if (lane == 0) out[cursor] = r + t.num_special;
             cursor += 1;
-        } else if (a.long_list && e - w0 >= (uint64_t)a.long_min && e - w0 <= TK_LONG_MAX && (a.long_force || tk_piece_repetitive(a, lane, w0, e))) {
-            // a LONG repetitive piece that is not a vocabulary key: thousands of dependent merges for one wave, many of them
-            // of the same rank.  The document goes to tk_long.hip, which merges such a piece in rounds by a workgroup
+        } else if (a.long_list && tk_piece_is_long(a, lane, w0, e) != 0u) {
+            // a LONG piece that is not a vocabulary key: thousands of dependent merges for one wave.  The document goes to
+            // tk_long.hip, which merges such a piece in rounds by a workgroup (all occurrences of a rank at once)
             if (lane == 0) {
                 a.counts[d] = 0;
                 a.long_list[wv_atomic_add(a.long_count, 1u)] = (uint32_t)d;

@@ -284,12 +284,289 @@ __device__ __forceinline__ uint32_t tkl_block_merge(const TkTablesView& t, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The LAZY form of the rounds, for long pieces with many distinct pairs (tools/batched_merge_model.py rounds_heads).
+//
+// On such a piece a rank has a dozen occurrences among 30 000 parts, and a round that compacts touches all of them: 25 us
+// of instruction issue on one CU, more than the dozen merges cost one at a time.  Here nothing moves: part i keeps slot i,
+// an alive bit says whether a part starts there, the pair ranks of all 32 K slots live in LDS (128 KB), and a round works
+// only where the minimum rank occurs:
+//   * every step of 64 slots keeps its minimum rank; r* = the minimum of the step minima; the steps whose minimum is r*
+//     are the only ones looked at;
+//   * of a run of consecutive candidates only the HEAD merges (no parity bookkeeping: neighbours are found by bit scans
+//     over the alive words); exactness needs, besides the cut behind the first occurrence that creates a pair below r*, the
+//     CHAIN cut: nothing to the right of the leftmost candidate whose two predecessors are candidates too (the sequential
+//     order would merge that one in this "round" as well; it waits for the next);
+//   * the heads become a per-wave list and are probed one lane per occurrence; the kept ones rewrite their slot, clear
+//     the alive bit of the part they swallow and note which steps changed; those steps' minima are recomputed.
+// Four workgroup barriers and two or three global round trips per round, whatever the length of the piece.
+// ------------------------------------------------------------------------------------------------------------------
+#define TKS_CAP 512                          /* occurrences a wave lists per round (more: the round is cut there) */
+#define TKS_STEPS (TK_LONG_MAX / 64)         /* 512 */
+#define TKS_WSTEPS (TKS_STEPS / TKL_WAVES)   /* steps owned by a wave: 32 */
+
+struct TksShared {
+    uint32_t rk[TK_LONG_MAX];                // rank of the pair (part at slot i, next alive part); MAX: none / dead slot
+    uint64_t alive[TKS_STEPS];
+    uint64_t hsel[TKS_STEPS];                // heads listed this round
+    uint32_t smin[TKS_STEPS];
+    uint32_t touched[TKL_WAVES];             // bit s of word w: step 32 w + s changed this round
+    uint16_t occ[TKL_WAVES][TKS_CAP];        // per wave: slots of its heads relative to its range, ascending
+    uint32_t wz[TKL_WAVES];                  // per wave: leftmost position nothing at or right of which may merge this round
+    uint32_t wunder[TKL_WAVES];
+    uint32_t wpop[TKL_WAVES];                // (output) alive parts per wave
+    uint32_t doc;
+};
+
+__device__ __forceinline__ int tks_next_alive(const uint64_t* alive, uint32_t G, uint32_t i) {
+    uint32_t g = i >> 6;
+    const uint32_t b = i & 63u;
+    uint64_t w = b == 63u ? 0ull : (alive[g] & (~0ull << (b + 1u)));
+    while (!w) {
+        if (++g >= G) return -1;
+        w = alive[g];
+    }
+    return (int)(64u * g + (uint32_t)__builtin_ctzll(w));
+}
+__device__ __forceinline__ int tks_prev_alive(const uint64_t* alive, uint32_t i) {
+    int g = (int)(i >> 6);
+    const uint32_t b = i & 63u;
+    uint64_t w = alive[g] & ((1ull << b) - 1ull);
+    while (!w) {
+        if (--g < 0) return -1;
+        w = alive[g];
+    }
+    return 64 * g + 63 - __builtin_clzll(w);
+}
+
+__device__ __forceinline__ uint32_t tks_block_merge(const TkTablesView& t, const uint8_t* bytes, uint32_t n0, uint32_t* scratch, uint32_t* out,
+                                                    TksShared& L) {
+    const int lane = wv_lane();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* tok = scratch;                                       // [n0] token of the part at slot i
+    uint32_t* Blr = scratch + n0;                                  // results of the occurrences beyond a wave's first 64
+    uint32_t* Brr = scratch + 2 * (size_t)n0;
+    const uint32_t G = (n0 + 63u) / 64u;                           // steps in use
+
+    // ---- start: one part per byte, pair ranks from PAIR2; step minima ----
+    for (uint32_t i = threadIdx.x; i < TKS_STEPS * 64u; i += TKL_THREADS) {
+        uint32_t r = TK_RANK_MAX;
+        if (i < n0) {
+            const uint32_t b0 = bytes[i];
+            tok[i] = b0;
+            if (i + 1u < n0) r = t.pair2[b0 | ((uint32_t)bytes[i + 1u] << 8)];
+        }
+        L.rk[i] = r;
+    }
+    for (uint32_t g = threadIdx.x; g < TKS_STEPS; g += TKL_THREADS) {
+        const uint32_t lo = 64u * g;
+        L.alive[g] = lo >= n0 ? 0ull : (n0 - lo >= 64u ? ~0ull : ((1ull << (n0 - lo)) - 1ull));
+        L.hsel[g] = 0ull;
+    }
+    if (threadIdx.x < TKL_WAVES) L.touched[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t s = 0; s < TKS_WSTEPS; ++s) {
+        const uint32_t g = wv * TKS_WSTEPS + s;
+        const uint32_t m = tkl_wave_min(L.rk[64u * g + (uint32_t)lane]);
+        if (lane == 0) L.smin[g] = m;
+    }
+    __syncthreads();
+
+    for (uint32_t round = 0; round <= n0; ++round) {               // (every round merges at least one pair)
+        // ---- a: r* ----
+        uint32_t rstar = TK_RANK_MAX;
+#pragma unroll
+        for (int q = 0; q < TKS_STEPS / 64; ++q) {
+            const uint32_t v = L.smin[64 * q + lane];
+            rstar = v < rstar ? v : rstar;
+        }
+        rstar = tkl_wave_min(rstar);
+        if (rstar == TK_RANK_MAX) break;                           // block-uniform
+
+        // ---- b: the heads of the wave's steps, the chain cut ----
+        uint16_t* occ = L.occ[wv];
+        uint32_t cntw = 0, zw = 0xFFFFFFFFu;
+        {
+            const uint32_t gq = wv * TKS_WSTEPS + (uint32_t)lane;
+            uint64_t act = wv_ballot(lane < TKS_WSTEPS && L.smin[lane < TKS_WSTEPS ? gq : 0u] == rstar);
+            while (act) {                                          // wave-uniform
+                const uint32_t s = (uint32_t)tk_ctz64(act);
+                act &= act - 1ull;
+                const uint32_t g = wv * TKS_WSTEPS + s;
+                const uint32_t i = 64u * g + (uint32_t)lane;
+                const bool c = L.rk[i] == rstar;                   // (a dead slot holds MAX)
+                bool head = false;
+                uint32_t zl = 0xFFFFFFFFu;
+                if (c) {
+                    const int p = tks_prev_alive(L.alive, i);
+                    const bool pc = p >= 0 && L.rk[p] == rstar;
+                    head = !pc;
+                    if (pc) {
+                        const int pp = tks_prev_alive(L.alive, (uint32_t)p);
+                        if (pp >= 0 && L.rk[pp] == rstar) zl = i;  // third of a run: nothing from here on merges this round
+                    }
+                }
+                zl = tkl_wave_min(zl);
+                zw = zl < zw ? zl : zw;
+                uint64_t H = wv_ballot(head);
+                if (cntw + (uint32_t)tk_popc64(H) > TKS_CAP) {     // the list is full: cut the round at the first head left out
+                    uint32_t keep = TKS_CAP - cntw;
+                    uint64_t K = 0ull, R = H;
+                    while (keep--) { K |= R & (~R + 1ull); R &= R - 1ull; }
+                    const uint32_t first_out = 64u * g + (uint32_t)tk_ctz64(R);
+                    zw = first_out < zw ? first_out : zw;
+                    H = K;
+                    act = 0ull;
+                }
+                if (tk_bit(H, lane)) occ[cntw + (uint32_t)tk_popc64(H & tk_lowmask(lane))] = (uint16_t)(64u * s + (uint32_t)lane);
+                if (lane == 0) L.hsel[g] = H;
+                cntw += (uint32_t)tk_popc64(H);
+            }
+            if (lane == 0) L.wz[wv] = zw;
+        }
+        __syncthreads();
+        uint32_t zcut = lane < TKL_WAVES ? L.wz[lane] : 0xFFFFFFFFu;
+        zcut = tkl_wave_min(zcut);
+        const uint32_t wbase = wv * TKS_WSTEPS * 64u;
+        if (zcut != 0xFFFFFFFFu) {                                 // the lists are ascending: a prefix stays
+            uint32_t kept = 0;
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+                const uint32_t k = k0 + (uint32_t)lane;
+                kept += (uint32_t)tk_popc64(wv_ballot(k < cntw && wbase + (uint32_t)occ[k < cntw ? k : 0u] < zcut));
+            }
+            cntw = kept;
+        }
+
+        // ---- c: one lane per occurrence: neighbours by bit scans, the two created pairs probed ----
+        uint32_t umin = 0xFFFFFFFFu;
+        uint32_t lr0 = TK_RANK_MAX, rr0 = TK_RANK_MAX;
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < cntw) {
+                const uint32_t i = wbase + (uint32_t)occ[k];
+                const int j = tks_next_alive(L.alive, G, i);       // exists: rk[i] is a rank
+                const int k2 = tks_next_alive(L.alive, G, (uint32_t)j);
+                const int p = tks_prev_alive(L.alive, i);
+                uint32_t tl = 0, tr = 0;
+                if (p >= 0) {
+                    const int pp = tks_prev_alive(L.alive, (uint32_t)p);
+                    // the part before me is swallowed this round if the occurrence before it is a listed head left of the cut
+                    const bool lm = pp >= 0 && tk_bit(L.hsel[pp >> 6], pp & 63) && (uint32_t)pp < zcut;
+                    tl = lm ? rstar : tok[p];
+                }
+                if (k2 >= 0) tr = tok[k2];
+                uint32_t lr = TK_RANK_MAX, rr = TK_RANK_MAX;
+                tk_probe_pair_x2(t, p >= 0 ? tl : 0u, rstar, rstar, k2 >= 0 ? tr : 0u, lr, rr);
+                if (p < 0) lr = TK_RANK_MAX;
+                if (k2 < 0) rr = TK_RANK_MAX;
+                if (k0 == 0u) { lr0 = lr; rr0 = rr; }
+                else { Blr[i] = lr; Brr[i] = rr; }
+                if (lr < rstar || rr < rstar) umin = i < umin ? i : umin;
+            }
+        }
+        umin = tkl_wave_min(umin);
+        if (lane == 0) L.wunder[wv] = umin;
+        __syncthreads();
+        uint32_t ustar = lane < TKL_WAVES ? L.wunder[lane] : 0xFFFFFFFFu;
+        ustar = tkl_wave_min(ustar);
+
+        // ---- d: the kept occurrences rewrite their slots (every rank slot has one writer: see tkl_block_merge R5) ----
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < cntw) {
+                const uint32_t i = wbase + (uint32_t)occ[k];
+                if (i <= ustar) {
+                    uint32_t lr = lr0, rr = rr0;
+                    if (k0 != 0u) { lr = Blr[i]; rr = Brr[i]; }
+                    const int j = tks_next_alive(L.alive, G, i);
+                    const int k2 = tks_next_alive(L.alive, G, (uint32_t)j);
+                    const int p = tks_prev_alive(L.alive, i);
+                    int left = p;
+                    if (p >= 0) {
+                        const int pp = tks_prev_alive(L.alive, (uint32_t)p);
+                        if (pp >= 0 && tk_bit(L.hsel[pp >> 6], pp & 63) && (uint32_t)pp < zcut) left = pp;   // (pp < i <= ustar)
+                    }
+                    const bool next_merges = k2 >= 0 && tk_bit(L.hsel[k2 >> 6], k2 & 63) && (uint32_t)k2 < zcut && (uint32_t)k2 <= ustar;
+                    // (the alive words are read above by every lane of the batch before any lane clears a bit below:
+                    //  the batch's reads and writes are separated by the wave's lockstep, the batches by wv_lds_sync)
+                    tok[i] = rstar;
+                    if (!next_merges) L.rk[i] = rr;
+                    if (left >= 0) L.rk[left] = lr;
+                    L.rk[j] = TK_RANK_MAX;
+                    // which steps changed
+                    atomicOr(&L.touched[(i >> 6) / TKS_WSTEPS], 1u << ((i >> 6) % TKS_WSTEPS));
+                    atomicOr(&L.touched[((uint32_t)j >> 6) / TKS_WSTEPS], 1u << (((uint32_t)j >> 6) % TKS_WSTEPS));
+                    if (left >= 0) atomicOr(&L.touched[((uint32_t)left >> 6) / TKS_WSTEPS], 1u << (((uint32_t)left >> 6) % TKS_WSTEPS));
+                    // the swallowed part: its alive bit goes LAST, after every lane of the round has looked its neighbours up
+                    Blr[i] = (uint32_t)j;                                      // (remembered for phase e)
+                }
+            }
+        }
+        __syncthreads();   // all neighbour look-ups of the round are done
+        // ---- e: clear the alive bits of the swallowed parts, recompute the minima of the steps that changed ----
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < cntw; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < cntw) {
+                const uint32_t i = wbase + (uint32_t)occ[k];
+                if (i <= ustar) {
+                    const uint32_t j = Blr[i];
+                    atomicAnd((unsigned long long*)&L.alive[j >> 6], ~(1ull << (j & 63u)));
+                }
+            }
+        }
+        {
+            const uint32_t g = wv * TKS_WSTEPS + (uint32_t)lane;
+            if (lane < TKS_WSTEPS) L.hsel[g] = 0ull;
+        }
+        __syncthreads();
+        {
+            uint32_t T = L.touched[wv];
+            while (T) {                                                // wave-uniform
+                const uint32_t s = (uint32_t)__builtin_ctz(T);
+                T &= T - 1u;
+                const uint32_t g = wv * TKS_WSTEPS + s;
+                const uint32_t m = tkl_wave_min(L.rk[64u * g + (uint32_t)lane]);
+                if (lane == 0) L.smin[g] = m;
+            }
+            if (lane == 0) L.touched[wv] = 0u;
+        }
+        __syncthreads();
+    }
+
+    // ---- the alive parts in order -> out ----
+    {
+        uint32_t cnt = 0;
+        for (uint32_t s = 0; s < TKS_WSTEPS; ++s) cnt += (uint32_t)tk_popc64(L.alive[wv * TKS_WSTEPS + s]);
+        if (lane == 0) L.wpop[wv] = cnt;
+    }
+    __syncthreads();
+    uint32_t at = 0, total = 0;
+    for (uint32_t v = 0; v < TKL_WAVES; ++v) {
+        const uint32_t c = L.wpop[v];
+        if (v < wv) at += c;
+        total += c;
+    }
+    for (uint32_t s = 0; s < TKS_WSTEPS; ++s) {
+        const uint32_t g = wv * TKS_WSTEPS + s;
+        const uint64_t A = L.alive[g];
+        if (tk_bit(A, lane)) out[at + (uint32_t)tk_popc64(A & tk_lowmask(lane))] = tok[64u * g + (uint32_t)lane] + t.num_special;
+        at += (uint32_t)tk_popc64(A);
+    }
+    __syncthreads();   // the scratch and the LDS are the next job's
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // The documents of the long list take three launches:
 //   tk_long_walk_kernel     one wave per document walks it piece by piece (sequential matcher, whole-piece lookup, the
 //                           single-wave merge for ordinary pieces) and writes the ids of the piece at byte offset p to
 //                           staging slot p (a piece of L bytes has at most L ids; the slots it does not use become
 //                           holes); a long piece that is not a vocabulary key becomes a JOB instead;
-//   tk_long_merge_kernel    one workgroup per job: the round-based merge above, ids (+ holes) into the piece's slots;
+//   tk_long_merge_kernel /  one workgroup per job: the round-based merge above (compacting rounds for repetitive pieces, lazy
+//   tk_long_sparse_kernel   rounds for the others), ids (+ holes) into the piece's slots;
 //   tk_long_compact_kernel  one wave per document squeezes the holes out, appends EOS and writes the id count.
 // (One fused kernel -- wave 0 walking, all waves joining for a long piece -- was the first form: the walker's 136 registers
 // under the 128 a 1024-thread block leaves a wave spilled 237 of them and dragged the round loop's arrays into scratch.)
@@ -321,12 +598,15 @@ __global__ __launch_bounds__(256) void tk_long_walk_kernel(TkEncodeArgs a) {
             if (r != TK_RANK_MAX) {
                 if (lane == 0) dst[0] = r + t.num_special;
                 cur = 1;
-            } else if (len >= a.long_min && len <= TK_LONG_MAX && (a.long_force || tk_piece_repetitive(a, lane, w0, e))) {
+            } else if (const uint32_t how = tk_piece_is_long(a, lane, w0, e)) {
+                // 1: repetitive (few distinct pairs: a rank has thousands of occurrences) -> the compacting rounds (kind 0);
+                // 2: many distinct pairs (a dozen occurrences per rank) and long enough -> the lazy rounds (kind 1)
+                const uint32_t kind = how - 1u;
                 if (lane == 0) {
                     const uint32_t slot = wv_atomic_add(a.long_job_count, 1u);
                     if (slot < a.long_job_cap) {
                         TkLongJob j;
-                        j.doc = (uint32_t)d; j.off = (uint32_t)(w0 - s0); j.len = len; j.pad = 0u;
+                        j.doc = (uint32_t)d; j.off = (uint32_t)(w0 - s0); j.len = len; j.pad = kind;
                         a.long_jobs[slot] = j;
                     }
                 }
@@ -352,9 +632,30 @@ __global__ __launch_bounds__(TKL_THREADS) void tk_long_merge_kernel(TkEncodeArgs
         __syncthreads();                                           // everybody has the ticket before it is overwritten
         if (q >= n_jobs) break;                                    // block-uniform
         const TkLongJob j = a.long_jobs[q];
+        if (j.pad != 0u) continue;                                 // (the lazy rounds take it: tk_long_sparse_kernel)
         const uint64_t s0 = a.doc_offs[j.doc];
         uint32_t* out = a.staging + s0 + 2ull * j.doc + base + j.off;
         const uint32_t n = tkl_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);
+        for (uint32_t i = n + threadIdx.x; i < j.len; i += TKL_THREADS) out[i] = TKL_HOLE;
+    }
+}
+
+__global__ __launch_bounds__(TKL_THREADS) void tk_long_sparse_kernel(TkEncodeArgs a) {
+    __shared__ TksShared L;
+    uint32_t* scratch = a.scratch + (size_t)blockIdx.x * a.scratch_words_per_wave;
+    const uint32_t n_jobs = *a.long_job_count < a.long_job_cap ? *a.long_job_count : a.long_job_cap;
+    const uint32_t base = a.add_bos ? 1u : 0u;
+    for (;;) {
+        if (threadIdx.x == 0) L.doc = atomicAdd(a.work_counter + 11, 1u);     // (its own ticket counter)
+        __syncthreads();
+        const uint32_t q = L.doc;
+        __syncthreads();
+        if (q >= n_jobs) break;                                    // block-uniform
+        const TkLongJob j = a.long_jobs[q];
+        if (j.pad != 1u) continue;
+        const uint64_t s0 = a.doc_offs[j.doc];
+        uint32_t* out = a.staging + s0 + 2ull * j.doc + base + j.off;
+        const uint32_t n = tks_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);
         for (uint32_t i = n + threadIdx.x; i < j.len; i += TKL_THREADS) out[i] = TKL_HOLE;
     }
 }
@@ -395,6 +696,7 @@ hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves
 hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s) {
     if (args.n_todo == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_long_merge_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
+    hipLaunchKernelGGL(tk_long_sparse_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
     hipLaunchKernelGGL(tk_long_compact_kernel, dim3(n_compact_blocks), dim3(256), 0, s, args);
     return hipGetLastError();
 }

@@ -109,6 +109,92 @@ def rounds(ranks, piece, stats=None):
     return parts
 
 
+def rounds_heads(ranks, piece, stats=None):
+    """The LAZY form (csrc/tk_long.hip, tk_long_sparse_kernel): parts are never compacted -- slot i keeps its place, an
+    alive flag says whether a part starts there -- and a round merges only the HEADS of the candidate runs (a candidate whose
+    predecessor is not a candidate), one lane each, without any run-parity bookkeeping.  Exactness needs two cuts:
+      * the undercut cut of `rounds` (a created pair below r*: nothing to the right of that occurrence merges this round);
+      * the CHAIN cut: in a run of three or more consecutive candidates the sequential order also merges the member at
+        offset 2 in this "round"; the lazy form leaves it for the next one, so nothing to the RIGHT of the leftmost such
+        member may merge before it (its merge could create a pair that undercuts and reaches into what lies to its right).
+    A run of k candidates therefore takes ~k / 2 rounds: the form for pieces with many distinct pairs, where runs are rare."""
+    n = len(piece)
+    tok = [piece[i:i + 1] for i in range(n)]
+    alive = [True] * n
+
+    def rk(a, b):
+        return ranks.get(a + b, MAX)
+
+    def nxt(i):
+        i += 1
+        while i < n and not alive[i]:
+            i += 1
+        return i
+
+    def prv(i):
+        i -= 1
+        while i >= 0 and not alive[i]:
+            i -= 1
+        return i
+
+    pair = [rk(tok[i], tok[i + 1]) if i + 1 < n else MAX for i in range(n)]
+    n_rounds = n_chain = n_cut = 0
+    while True:
+        live = [i for i in range(n) if alive[i]]
+        r_star = min((pair[i] for i in live), default=MAX)
+        if r_star >= MAX:
+            break
+        n_rounds += 1
+        cand = {i for i in live if pair[i] == r_star}
+        heads = [i for i in sorted(cand) if prv(i) not in cand]
+        # chain cut: leftmost candidate whose two predecessors are candidates too
+        z = min((i for i in cand if prv(i) in cand and prv(prv(i)) in cand), default=n)
+        if z < n:
+            n_chain += 1
+        heads = [i for i in heads if i < z]
+        headset = set(heads)
+        res = {}
+        under = []
+        for i in heads:                                   # the parallel part: one lane per head
+            j = nxt(i)
+            k = nxt(j)
+            p = prv(i)
+            merged = tok[i] + tok[j]
+            lr = rr = MAX
+            left_slot = -1
+            if p >= 0:
+                pp = prv(p)
+                if pp >= 0 and pp in headset and nxt(pp) == p:      # p is consumed by the occurrence before it
+                    left, left_slot = tok[pp] + tok[p], pp
+                else:
+                    left, left_slot = tok[p], p
+                lr = rk(left, merged)
+            if k < n:
+                rr = rk(merged, tok[k])
+            res[i] = (j, k, left_slot, lr, rr, merged)
+            if lr < r_star or rr < r_star:
+                under.append(i)
+        if under:
+            n_cut += 1
+            u = min(under)
+            heads = [i for i in heads if i <= u]
+            headset = set(heads)
+        for i in heads:
+            j, k, left_slot, lr, rr, merged = res[i]
+            tok[i] = merged
+            alive[j] = False
+            pair[j] = MAX
+            if not (k < n and k in headset):              # the pair behind me: mine unless the next occurrence starts right there
+                pair[i] = rr
+            if left_slot >= 0:
+                pair[left_slot] = lr
+    if stats is not None:
+        stats["rounds"] = stats.get("rounds", 0) + n_rounds
+        stats["chain_rounds"] = stats.get("chain_rounds", 0) + n_chain
+        stats["cut_rounds"] = stats.get("cut_rounds", 0) + n_cut
+    return [tok[i] for i in range(n) if alive[i]]
+
+
 def _random_vocab(rng, alphabet, n_extra, max_len):
     toks = {bytes([b]): b for b in range(256)}
     words = []
@@ -127,7 +213,7 @@ def _random_vocab(rng, alphabet, n_extra, max_len):
 
 def self_check(n_vocabs=40, n_pieces=60, seed=5):
     rng = random.Random(seed)
-    stats = {}
+    stats, stats2 = {}, {}
     checked = 0
     for v in range(n_vocabs):
         alphabet = rng.choice(["ab", "abc", "a", "abcd", "ab"])
@@ -137,7 +223,10 @@ def self_check(n_vocabs=40, n_pieces=60, seed=5):
             piece = "".join(rng.choice(alphabet) for _ in range(n)).encode()
             a, b = sequential(ranks, piece), rounds(ranks, piece, stats)
             assert a == b, (alphabet, piece, a, b)
+            c = rounds_heads(ranks, piece, stats2)
+            assert a == c, ("lazy form", alphabet, piece, a, c)
             checked += 1
+    stats["lazy"] = stats2
     return checked, stats
 
 
@@ -145,3 +234,6 @@ if __name__ == "__main__":
     c, st = self_check()
     print("round-based merge == sequential merge on %d pieces; rounds %d, of which cut short by an undercutting pair %d"
           % (c, st["rounds"], st["cut_rounds"]))
+    lz = st["lazy"]
+    print("lazy (heads-only) form == sequential merge on the same pieces; rounds %d, chain cuts %d, undercut cuts %d"
+          % (lz["rounds"], lz["chain_rounds"], lz["cut_rounds"]))

@@ -346,7 +346,7 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
             const uint64_t fit = budget_words / words >= 4 ? budget_words / words : 4;   // scratch slices the budget allows
             uint64_t walk_waves = ((n_long < 1024u ? n_long : 1024u) + 3) / 4 * 4;
-            uint64_t blocks = (uint64_t)2 * cus;                                   // two 16-wave blocks fill a CU
+            uint64_t blocks = (uint64_t)cus;                                       // one 16-wave block per CU (158 KB of LDS)
             if (walk_waves > fit) walk_waves = fit / 4 * 4;
             if (blocks > fit) blocks = fit;
             TK_HIP(c, c->scratch.reserve((walk_waves > blocks ? walk_waves : blocks) * words * 4));   // (pass 2 is complete: its slices are free)
@@ -364,8 +364,7 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
             TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
             TK_HIP(c, hipMemsetAsync(d_job_count, 0, 4, s));
             TK_HIP(c, tk_launch_encode_long(b, (uint32_t)walk_waves, 0, s));
-            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counters (one per merge kernel)
-            TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 11, 0, 4, s));
+            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counter
             const uint64_t cblocks = (n_long + 3) / 4 < 4096 ? (n_long + 3) / 4 : 4096;
             TK_HIP(c, tk_launch_encode_long_merge(b, (uint32_t)blocks, (uint32_t)cblocks, s));
             if (dbg) { TK_HIP(c, hipStreamSynchronize(s)); fprintf(stderr, "[tk] round-based kernels done: %u documents\n", n_long); }

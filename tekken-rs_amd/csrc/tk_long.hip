@@ -565,8 +565,8 @@ __device__ __forceinline__ uint32_t tks_block_merge(const TkTablesView& t, const
 //                           single-wave merge for ordinary pieces) and writes the ids of the piece at byte offset p to
 //                           staging slot p (a piece of L bytes has at most L ids; the slots it does not use become
 //                           holes); a long piece that is not a vocabulary key becomes a JOB instead;
-//   tk_long_merge_kernel /  one workgroup per job: the round-based merge above (compacting rounds for repetitive pieces, lazy
-//   tk_long_sparse_kernel   rounds for the others), ids (+ holes) into the piece's slots;
+//   tk_long_merge_kernel    one workgroup per job: the round-based merge above (compacting rounds for repetitive pieces, lazy
+//                           rounds for the others), ids (+ holes) into the piece's slots;
 //   tk_long_compact_kernel  one wave per document squeezes the holes out, appends EOS and writes the id count.
 // (One fused kernel -- wave 0 walking, all waves joining for a long piece -- was the first form: the walker's 136 registers
 // under the 128 a 1024-thread block leaves a wave spilled 237 of them and dragged the round loop's arrays into scratch.)
@@ -620,42 +620,27 @@ __global__ __launch_bounds__(256) void tk_long_walk_kernel(TkEncodeArgs a) {
     }
 }
 
+// one kernel for both kinds of job (a workgroup takes whatever comes next: the long jobs of both kinds run side by side);
+// the two forms share the block's LDS
 __global__ __launch_bounds__(TKL_THREADS) void tk_long_merge_kernel(TkEncodeArgs a) {
-    __shared__ TklShared L;
+    __shared__ TksShared LS;
+    TklShared& L = *reinterpret_cast<TklShared*>(&LS);
+    static_assert(sizeof(TklShared) <= sizeof(TksShared), "the compacting form's LDS fits inside the lazy form's");
     uint32_t* scratch = a.scratch + (size_t)blockIdx.x * a.scratch_words_per_wave;
     const uint32_t n_jobs = *a.long_job_count < a.long_job_cap ? *a.long_job_count : a.long_job_cap;
     const uint32_t base = a.add_bos ? 1u : 0u;
     for (;;) {
-        if (threadIdx.x == 0) L.doc = atomicAdd(a.work_counter, 1u);
+        if (threadIdx.x == 0) LS.doc = atomicAdd(a.work_counter, 1u);
         __syncthreads();
-        const uint32_t q = L.doc;
+        const uint32_t q = LS.doc;
         __syncthreads();                                           // everybody has the ticket before it is overwritten
         if (q >= n_jobs) break;                                    // block-uniform
         const TkLongJob j = a.long_jobs[q];
-        if (j.pad != 0u) continue;                                 // (the lazy rounds take it: tk_long_sparse_kernel)
         const uint64_t s0 = a.doc_offs[j.doc];
         uint32_t* out = a.staging + s0 + 2ull * j.doc + base + j.off;
-        const uint32_t n = tkl_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);
-        for (uint32_t i = n + threadIdx.x; i < j.len; i += TKL_THREADS) out[i] = TKL_HOLE;
-    }
-}
-
-__global__ __launch_bounds__(TKL_THREADS) void tk_long_sparse_kernel(TkEncodeArgs a) {
-    __shared__ TksShared L;
-    uint32_t* scratch = a.scratch + (size_t)blockIdx.x * a.scratch_words_per_wave;
-    const uint32_t n_jobs = *a.long_job_count < a.long_job_cap ? *a.long_job_count : a.long_job_cap;
-    const uint32_t base = a.add_bos ? 1u : 0u;
-    for (;;) {
-        if (threadIdx.x == 0) L.doc = atomicAdd(a.work_counter + 11, 1u);     // (its own ticket counter)
-        __syncthreads();
-        const uint32_t q = L.doc;
-        __syncthreads();
-        if (q >= n_jobs) break;                                    // block-uniform
-        const TkLongJob j = a.long_jobs[q];
-        if (j.pad != 1u) continue;
-        const uint64_t s0 = a.doc_offs[j.doc];
-        uint32_t* out = a.staging + s0 + 2ull * j.doc + base + j.off;
-        const uint32_t n = tks_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);
+        uint32_t n;
+        if (j.pad == 0u) n = tkl_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, L);     // repetitive: compacting rounds
+        else n = tks_block_merge(a.t, a.bytes + s0 + j.off, j.len, scratch, out, LS);               // many distinct pairs: lazy rounds
         for (uint32_t i = n + threadIdx.x; i < j.len; i += TKL_THREADS) out[i] = TKL_HOLE;
     }
 }
@@ -696,7 +681,6 @@ hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves
 hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s) {
     if (args.n_todo == 0) return hipSuccess;
     hipLaunchKernelGGL(tk_long_merge_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
-    hipLaunchKernelGGL(tk_long_sparse_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
     hipLaunchKernelGGL(tk_long_compact_kernel, dim3(n_compact_blocks), dim3(256), 0, s, args);
     return hipGetLastError();
 }

@@ -76,6 +76,17 @@ def test_emu_flat_baseline_shapes(test_vocab):
         _emu_check(test_vocab, helpers.EDGE_DOCS, bos, eos)
 
 
+def test_emu_flat_sparse_miss_queues(test_vocab):
+    """A few queued pieces in ~300 chunks: the later items of a merge wave lie more than three 64-entry windows of
+    sub-queues behind the first, so the wave finds them by bisection (csrc/tk_flat_impl.h tk_merge_wave), narrow and wide."""
+    filler = b"a\nb\nc\nd\ne\nf\ng\nh\ni\nj\nk\nl\nm\nn\no\np\nq\nr\ns\nt\nu\nv\nw\nx\ny\nz\n" * 40      # one-byte pieces: never queued
+    docs = [filler] * 290
+    for d, w in ((0, b"qzxjv"), (140, b"kqjxzvwpyfbg"), (280, b"zqxjkvbwpfgmhdcylrtn"), (3, b"xzqjvkwbpfmgyhdclrtnxzqjvkwbpfmgyhdclrtn"),
+                 (285, b"jqzxv"), (288, b"vkqjxzwpbfgyhmdclrtnsaeio")):
+        docs[d] = filler[:520] + w + b"\n" + filler[520:]
+    assert _emu_check(test_vocab, docs) == []
+
+
 def test_emu_flat_handback_and_mixed(test_vocab):
     docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120)
     flagged = _emu_check(test_vocab, docs)

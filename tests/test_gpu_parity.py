@@ -593,6 +593,32 @@ def test_merge_kernels_every_piece_length(tk, eng_small, eng_bench, test_vocab, 
             check_batch(eng, orc, data, offs, bos, eos)
 
 
+def test_sparse_miss_queues(tk, eng_bench, bench_vocab):
+    """Few queued pieces in many chunks: the 64 items of a merge wave then span thousands of per-chunk sub-queues (the wave
+    finds them by a window over the prefix sums, then by bisection: csrc/tk_flat_impl.h tk_merge_wave); every length class,
+    also with one single queued piece in the whole batch."""
+    import random
+    rng = random.Random(99)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    bdocs = corpus.docs_of(*corpus.generate("ascii", 20000, 512, seed=corpus.BASE_SEED + 31))
+    orc = helpers.oracle_for(bench_vocab)
+    for every, lens in ((331, (5, 12, 24, 48)), (2917, (24,)), (19999, (40,)), (700, (20, 28, 60))):
+        docs = list(bdocs)
+        for d in range(every - 1, len(docs), every):
+            n = lens[(d // every) % len(lens)]
+            docs[d] = docs[d][:200] + b" " + "".join(rng.choice(letters) for _ in range(n)).encode() + b" " + docs[d][200:]
+        data, offs = tk.pack_docs(docs)
+        check_batch(eng_bench, orc, data, offs)
+    # one-byte pieces never miss: the narrow queues are as sparse as the wide ones
+    filler = "".join(c + "\n" for c in letters).encode() * 40
+    docs = [filler] * 3000
+    for d in range(0, 3000, 409):
+        n = (3, 7, 12, 16, 20, 31, 40, 64)[(d // 409) % 8]
+        docs[d] = filler[:520] + "".join(rng.choice(letters) for _ in range(n)).encode() + b"\n" + filler[520:]
+    data, offs = tk.pack_docs(docs)
+    check_batch(eng_bench, orc, data, offs)
+
+
 def test_small_batches_one_launch(tk, test_vocab, bench_vocab):
     """tk_encode_one and small tk_encode_batch calls (<= 1024 documents, <= 64 KiB) run as ONE launch (tk_small_kernel);
     ids identical to the oracle, a document that needs pass 2 falls back,

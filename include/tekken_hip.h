@@ -237,6 +237,14 @@ int tk_tokenizer_decode_batch(tk_tokenizer* t, const uint32_t* ids, const uint64
 int tk_tokenizer_decode(tk_tokenizer* t, const uint32_t* ids, size_t n_ids, int policy, char** text,
                         size_t* len);
 void tk_free_text(char* text);
+/* Tekkenizer::decode_all (src/tekkenizer.rs:463-560): the segments decode() joins, one per run of special / non-special
+ * ids -- *text holds them back to back (tk_free_text), seg_ends[i] (tk_free_offsets) is the END of segment i in *text. */
+int tk_tokenizer_decode_all(tk_tokenizer* t, const uint32_t* ids, size_t n_ids, int policy, char** text, uint64_t** seg_ends,
+                            size_t* n_segments);
+void tk_free_offsets(uint64_t* offsets);
+/* Tekkenizer::vocab (src/tekkenizer.rs:348-350): the piece string of every id, specials included, back to back in *text;
+ * ends[id] is where the piece of `id` ends (vocab_size entries). */
+int tk_tokenizer_vocab(tk_tokenizer* t, char** text, uint64_t** ends, size_t* n_pieces);
 
 /* Accessors (src/tekkenizer.rs:260-350, 574-600, 617-695). */
 uint32_t tk_tokenizer_vocab_size(const tk_tokenizer* t);

@@ -163,6 +163,14 @@ def lib():
     L.tk_tokenizer_decode.argtypes = [vp, u32p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_size_t)]
     L.tk_free_text.argtypes = [ctypes.c_void_p]
+    u64pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint64))
+    L.tk_free_offsets.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.tk_free_offsets.restype = None
+    L.tk_tokenizer_decode_all.restype = ctypes.c_int
+    L.tk_tokenizer_decode_all.argtypes = [vp, u32p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), u64pp,
+                                          ctypes.POINTER(ctypes.c_size_t)]
+    L.tk_tokenizer_vocab.restype = ctypes.c_int
+    L.tk_tokenizer_vocab.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), u64pp, ctypes.POINTER(ctypes.c_size_t)]
     L.tk_tokenizer_vocab_size.restype = ctypes.c_uint32
     L.tk_tokenizer_vocab_size.argtypes = [vp]
     L.tk_tokenizer_num_special_tokens.restype = ctypes.c_uint32
@@ -594,6 +602,29 @@ class Tekkenizer:
         out = ctypes.string_at(text, n.value).decode("utf-8")
         lib().tk_free_text(text)
         return out
+
+    def _strs(self, fn, *args):
+        text = ctypes.c_void_p()
+        ends = ctypes.POINTER(ctypes.c_uint64)()
+        n = ctypes.c_size_t(0)
+        rc = fn(self._h, *args, ctypes.byref(text), ctypes.byref(ends), ctypes.byref(n))
+        if rc != TK_OK:
+            raise self._err(rc)
+        e = [int(ends[i]) for i in range(n.value)]
+        raw = ctypes.string_at(text, e[-1] if e else 0)
+        lib().tk_free_text(text)
+        lib().tk_free_offsets(ends)
+        return [raw[a:b].decode("utf-8") for a, b in zip([0] + e[:-1], e)]
+
+    def decode_all(self, ids, policy=SpecialTokenPolicy.Ignore):
+        """Tekkenizer::decode_all (src/tekkenizer.rs:463-560): one string per run of special / non-special ids."""
+        arr = np.ascontiguousarray(ids, dtype=np.uint32)
+        buf = arr if len(arr) else np.zeros(1, np.uint32)
+        return self._strs(lib().tk_tokenizer_decode_all, _p(buf, ctypes.c_uint32), len(arr), int(policy))
+
+    def vocab(self):
+        """Tekkenizer::vocab (src/tekkenizer.rs:348-350): the piece string of every id."""
+        return self._strs(lib().tk_tokenizer_vocab)
 
     def decode_batch(self, id_lists, policy=SpecialTokenPolicy.Ignore):
         """Batch decode on the GPU: list of id lists -> list of str (an addition; the reference decodes one at a time)."""

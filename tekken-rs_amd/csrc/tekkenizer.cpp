@@ -960,6 +960,37 @@ extern "C" int tk_tokenizer_decode(tk_tokenizer* h, const uint32_t* ids, size_t 
 }
 
 extern "C" void tk_free_text(char* text) { free(text); }
+extern "C" void tk_free_offsets(uint64_t* offsets) { free(offsets); }
+
+static int export_strs(tk_tokenizer* h, const std::vector<std::string>& parts, char** text, uint64_t** ends, size_t* n) {
+    std::string all;
+    uint64_t* e = (uint64_t*)malloc(sizeof(uint64_t) * (parts.size() + 1));
+    if (!e) { h->err = "out of memory"; return TK_ERR_RUNTIME; }
+    for (size_t i = 0; i < parts.size(); ++i) {
+        all += parts[i];
+        e[i] = all.size();
+    }
+    size_t len = 0;
+    int rc = export_str(h, all, text, &len);
+    if (rc != TK_OK) { free(e); return rc; }
+    *ends = e;
+    *n = parts.size();
+    return TK_OK;
+}
+
+extern "C" int tk_tokenizer_decode_all(tk_tokenizer* h, const uint32_t* ids, size_t n_ids, int policy, char** text,
+                                       uint64_t** seg_ends, size_t* n_segments) {
+    if (!h || !text || !seg_ends || !n_segments || (!ids && n_ids) || policy < 0 || policy > 2) return TK_ERR_INVALID_ARG;
+    std::vector<std::string> parts;
+    tekken::TokenizerError e = h->t->decode_all(ids, n_ids, (tekken::SpecialTokenPolicy)policy, parts);
+    if (!e.ok()) return finish(h, e);
+    return export_strs(h, parts, text, seg_ends, n_segments);
+}
+
+extern "C" int tk_tokenizer_vocab(tk_tokenizer* h, char** text, uint64_t** ends, size_t* n_pieces) {
+    if (!h || !text || !ends || !n_pieces) return TK_ERR_INVALID_ARG;
+    return export_strs(h, h->t->vocab(), text, ends, n_pieces);
+}
 
 extern "C" int tk_tokenizer_decode_batch(tk_tokenizer* h, const uint32_t* ids, const uint64_t* id_offsets, uint64_t n_docs,
                                          int policy, tk_text_result* out, uint64_t* bad_doc) {

@@ -61,6 +61,26 @@ def test_decode_policies(tk, small):
         small.decode([5000], P.Ignore)                            # unknown rank
 
 
+def test_decode_all_and_vocab(tk, small):
+    # reference src/tekkenizer.rs:463-560: one element per run of non-special ids, one per special id under Keep,
+    # nothing for a special run under Ignore, an error under Raise
+    P = tk.SpecialTokenPolicy
+    ids = [1, 1, 266, 42, 267, 2, 266, 3]
+    assert small.decode_all(ids, P.Keep) == ["<s>", "<s>", "hello world", "</s>", "hello", small.id_to_piece(3)]
+    assert small.decode_all(ids, P.Ignore) == ["hello world", "hello"]
+    assert small.decode_all([], P.Raise) == [] and small.decode_all([266, 267], P.Raise) == ["helloworld"]
+    with pytest.raises(tk.TokenizerError) as e:
+        small.decode_all(ids, P.Raise)
+    assert e.value.kind == "SpecialTokenPolicy"
+    assert "".join(small.decode_all(ids, P.Keep)) == small.decode(ids, P.Keep)
+    # src/tekkenizer.rs:348-350: index = id, specials first, then the (lossy) string of every rank
+    v = small.vocab()
+    assert len(v) == small.vocab_size() == 268
+    assert v[1] == "<s>" and v[266] == "hello" and v[267] == "world" and v[10 + ord("a")] == "a"
+    assert all(v[i] == small.id_to_piece(i) for i in list(range(10 + 0x80)) + [266, 267])
+    assert v[10 + 0x80] == "\ufffd"            # a lone continuation byte: the lossy string (src/tekkenizer.rs:150-160); id_to_piece fails there
+
+
 def test_id_to_piece(tk, small):
     # reference src/tekkenizer.rs:617-695 ; tests/test_tokenizer_detailed.rs:15-55
     P = tk.SpecialTokenPolicy

@@ -115,6 +115,7 @@ struct tk_ctx {
     int pattern = 0;               // tk_ctx_set_pattern: 0 the reference's hard-coded pattern, 1 the JSON pattern (row f-3)
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
+    DevBuf t_inline, t_len8;   // decode: 16-byte inline entries and one-byte lengths by rank (built at the first decode call)
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
     DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
@@ -260,7 +261,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
-                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi,
+                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->t_inline, &c->t_len8,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->long_list, &c->long_jobs, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
@@ -1111,6 +1112,23 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     TK_HIP(c, c->dec_err.reserve(64));
     TK_HIP(c, c->dec_hi.reserve((n_docs + 1) * 4));
     TK_HIP(c, c->block_sums.reserve((n_docs / 2048 + 4) * 8));
+    if (!c->t_inline.p) {
+        // by rank: the token's bytes and length in ONE 16-byte entry (tokens of up to 15 bytes), and the length alone in a byte
+        const TkHostTables& h = c->host;
+        std::vector<uint8_t> inl((size_t)h.n_ranks * 16 + 16, 0), l8((size_t)h.n_ranks + 16, 0);
+        for (uint32_t r = 0; r < h.n_ranks; ++r) {
+            const uint32_t len = h.offs[r + 1] - h.offs[r];
+            l8[r] = (uint8_t)(len < 255u ? len : 255u);
+            if (len <= 15u) {
+                memcpy(&inl[(size_t)r * 16], h.blob.data() + h.offs[r], len);
+                inl[(size_t)r * 16 + 15] = (uint8_t)len;
+            } else {
+                inl[(size_t)r * 16 + 15] = 0xFFu;
+            }
+        }
+        int rcu;
+        if ((rcu = upload(c, c->t_inline, inl.data(), inl.size())) || (rcu = upload(c, c->t_len8, l8.data(), l8.size()))) return rcu;
+    }
     TkDecodeArgs a;
     memset(&a, 0, sizeof(a));
     a.ids = d_ids;
@@ -1123,6 +1141,8 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.doc_hi = (uint32_t*)c->dec_hi.p;
     a.tok_blob = (const uint8_t*)c->t_blob.p;
     a.tok_offs = (const uint32_t*)c->t_offs.p;
+    a.tok_inline = (const uint8_t*)c->t_inline.p;
+    a.tok_len8 = (const uint8_t*)c->t_len8.p;
     a.sp_blob = (const uint8_t*)c->t_spblob.p;
     a.sp_offs = (const uint32_t*)c->t_spoffs.p;
     a.n_ranks = c->host.n_ranks;

@@ -9,7 +9,7 @@
 // GPU formulation (byte/index work, HBM-bound):
 //   tk_decode_doclen_kernel  one wave per document, one lane per id: text length of the document + error flags
 //   (tk_scan_*)              exclusive scan of the document lengths -> out_offsets (u64)
-//   tk_decode_emit_kernel    one wave per document, 64 ids at a time: in-register prefix sum, token bytes
+//   tk_decode_emit_kernel    one wave per 16 consecutive documents, their ids as one stream, 64 at a time: in-register prefix sum, token bytes
 //                            scattered into a per-wave LDS image of the chunk's span, streamed out with
 //                            aligned coalesced dword stores; ids that start a run mark a bit in a bitmap
 //   tk_decode_validate_kernel one lane per output byte: UTF-8 well-formedness where run starts and
@@ -45,11 +45,36 @@ __device__ __forceinline__ uint32_t tkd_wave_sum(uint32_t v) {
     return v;
 }
 
-// pass A: one wave per document, one lane per id: the document's text length + error flags
-__global__ __launch_bounds__(TKD_BLOCK) void tk_decode_doclen_kernel(TkDecodeArgs a) {
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts: VALU only; six ds_bpermute round trips of
+// __shfl_up were a third of a step's latency)
+__device__ __forceinline__ uint32_t tkd_scan_incl(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
+#define TKD_DOCS 16u          /* consecutive documents a wave takes as one stream of ids */
+#define TKD_L8_LDS 32768u     /* one-byte lengths of the ranks below this live in LDS (99 % of the ids of running text) */
+
+// pass A: the text length of every document + error flags: one wave per document, one lane per id; the length of a token
+// comes from an LDS copy of the one-byte length table (a gather from LDS costs a twelfth of one from the L2, and the
+// gathers were all this pass paid for).  (Sixteen documents per wave as one id stream with segmented sums -- the emit
+// kernel's form -- was slower here: 0.52 ms against 0.34, the bookkeeping outweighs the idle lanes.)
+#define TKD_LEN_BLOCK 1024     /* 16 waves share one LDS copy of the table: two blocks fill a CU's wave slots */
+__global__ __launch_bounds__(TKD_LEN_BLOCK) void tk_decode_doclen_kernel(TkDecodeArgs a) {
+    __shared__ uint32_t l8w[TKD_L8_LDS / 4];
+    const uint32_t n_lds = a.n_ranks < TKD_L8_LDS ? a.n_ranks : TKD_L8_LDS;
+    for (uint32_t q = threadIdx.x; q < (n_lds + 3u) / 4u; q += TKD_LEN_BLOCK) l8w[q] = reinterpret_cast<const uint32_t*>(a.tok_len8)[q];
+    __syncthreads();
+    const uint8_t* l8 = reinterpret_cast<const uint8_t*>(l8w);
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_BLOCK / 64);
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKD_LEN_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_LEN_BLOCK / 64);
     for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
         const uint64_t i0 = a.id_offs[d], i1 = a.id_offs[d + 1];
         uint32_t acc = 0;
@@ -57,13 +82,19 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_doclen_kernel(TkDecodeArg
             const uint32_t id = a.ids[i];
             if (id < a.num_special) {
                 if (a.policy == TK_POLICY_RAISE) atomicMin(a.err + 0, (unsigned long long)i);
-            } else if (id - a.num_special >= a.n_ranks) {
-                atomicMin(a.err + 1, (unsigned long long)i);
+                if (a.policy == TK_POLICY_KEEP) acc += a.sp_offs[id + 1] - a.sp_offs[id];
+            } else {
+                const uint32_t r = id - a.num_special;
+                if (r >= a.n_ranks) {
+                    atomicMin(a.err + 1, (unsigned long long)i);
+                } else {
+                    uint32_t len = r < TKD_L8_LDS ? (uint32_t)l8[r] : (uint32_t)a.tok_len8[r];
+                    if (len == 0xFFu) len = a.tok_offs[r + 1] - a.tok_offs[r];
+                    acc += len;
+                }
             }
-            const uint8_t* src;
-            acc += tkd_piece(a, id, &src);
         }
-        acc = tkd_wave_sum(acc);
+        acc = (uint32_t)__builtin_amdgcn_readlane((int)tkd_scan_incl(acc), 63);
         if (lane == 0) a.lens[d] = acc;
     }
 }
@@ -74,6 +105,16 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_doclen_kernel(TkDecodeArg
 // first / last partial dword of a span is written byte-wise.  ids that start a run mark a bit for the
 // UTF-8 pass.
 #define TKD_IMG_BYTES 4096u
+typedef uint32_t __attribute__((ext_vector_type(4))) tkd_u32x4;
+
+// the inline entry of id (zeros for a special / out-of-range id: such an id takes the slow path of its step)
+__device__ __forceinline__ tkd_u32x4 tkd_entry(const TkDecodeArgs& a, uint32_t id, bool have) {
+    tkd_u32x4 v = {0u, 0u, 0u, 0xFF000000u};
+    const uint32_t r = id - a.num_special;
+    if (have && id >= a.num_special && r < a.n_ranks) v = *reinterpret_cast<const tkd_u32x4*>(a.tok_inline + 16ull * r);
+    return v;
+}
+
 __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs a) {
     __shared__ uint32_t img_all[(TKD_BLOCK / 64) * (TKD_IMG_BYTES / 4 + 2)];
     const int lane = threadIdx.x & 63;
@@ -81,48 +122,90 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     uint8_t* img8 = reinterpret_cast<uint8_t*>(img);
     const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_BLOCK / 64);
-    for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
-        const uint64_t i0 = a.id_offs[d], i1 = a.id_offs[d + 1];
-        uint64_t cursor = a.out_offs[d];
+    // A wave takes TKD_DOCS consecutive documents as ONE stream of ids: the text of consecutive documents is contiguous
+    // (out_offs is the running sum of the lengths), so the 64-id steps run across the document boundaries -- full lanes
+    // (a 98-id document alone fills 77 % of two steps) and no per-document loads.  The loads of a step are issued two
+    // steps (ids) and one step (entries) ahead: a step waits for nothing that was not requested a whole step earlier.
+    for (uint64_t dA = wave * TKD_DOCS; dA < a.n_docs; dA += n_waves * TKD_DOCS) {
+        const uint64_t dB = dA + TKD_DOCS < a.n_docs ? dA + TKD_DOCS : a.n_docs;
+        const uint64_t i0 = a.id_offs[dA], i1 = a.id_offs[dB];
+        uint64_t cursor = a.out_offs[dA];
         bool hi_any = false;                       // some byte >= 0x80 among the token bytes this lane emitted
+        uint32_t id0 = i0 + (uint64_t)lane < i1 ? a.ids[i0 + lane] : 0u;
+        uint32_t id1 = i0 + 64 + (uint64_t)lane < i1 ? a.ids[i0 + 64 + lane] : 0u;
+        tkd_u32x4 e0 = tkd_entry(a, id0, i0 + (uint64_t)lane < i1);
+        uint32_t prev_last = a.num_special;        // the id before the step's first one (none before the group: not special)
         for (uint64_t c0 = i0; c0 < i1; c0 += 64) {
             const uint64_t i = c0 + (uint64_t)lane;
+            const uint32_t id2 = i + 128 < i1 ? a.ids[i + 128] : 0u;            // two steps ahead
+            const tkd_u32x4 e1 = tkd_entry(a, id1, i + 64 < i1);                 // one step ahead
+            const uint32_t id = id0;
+            // the id in front of this lane's (lane 0: the last id of the step before) -- all lanes take part
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_last, (int)id, 0x138, 0xF, 0xF, false);  // wave_shr:1
             const uint8_t* src = nullptr;
             uint32_t len = 0;
             bool mark = false;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};          // the token's first 16 bytes
             if (i < i1) {
-                const uint32_t id = a.ids[i];
-                len = tkd_piece(a, id, &src);
+                const uint32_t l = e0.w >> 24;
+                if (l != 0xFFu) {
+                    // ONE 16-byte gather gave the bytes and the length of a token of up to 15 bytes (all but a few hundred
+                    // of a 130 k vocabulary): offsets pair -> bytes was two dependent gathers
+                    len = l;
+                    w[0] = e0.x; w[1] = e0.y; w[2] = e0.z; w[3] = e0.w & 0x00FFFFFFu;
+                } else {
+                    len = tkd_piece(a, id, &src);      // special ids, long tokens, ids out of range
+                    if (len && len <= 16u) {
+                        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_u;
+                        const u32x4_u v = *reinterpret_cast<const u32x4_u*>(src);
+                        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                    }
+                }
                 // run starts (superset): every special id and every id that follows one
-                mark = id < a.num_special || (i > i0 && a.ids[i - 1] < a.num_special);
+                mark = id < a.num_special || (i > i0 && before < a.num_special);
             }
-            uint32_t incl = len;  // inclusive prefix sum over the 64 lanes
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t o = __shfl_up(incl, dd);
-                if (lane >= dd) incl += o;
-            }
-            const uint32_t span = __shfl(incl, 63);
+            prev_last = (uint32_t)__builtin_amdgcn_readlane((int)id, 63);
+            const uint32_t incl = tkd_scan_incl(len);
+            const uint32_t span = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint64_t dst = cursor + (incl - len);
             if (mark) atomicOr(a.run_bits + (dst >> 5), 1u << (dst & 31));
             const uint64_t base = cursor, end = cursor + span, g0 = base & ~3ull;
             if (end - g0 <= TKD_IMG_BYTES) {
                 const uint32_t off = (uint32_t)(dst - g0);
                 if (len <= 16u) {
-                    // one 16-byte load of the token bytes (the blobs carry >= 16 bytes of slack), then byte stores into
-                    // the LDS image from registers: a per-byte global gather costs the L1 a lane per clock and byte
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    if (len) {
-                        typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_u;
-                        const u32x4_u v = *reinterpret_cast<const u32x4_u*>(src);
-                        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                    }
+                    // the token bytes are in registers.  They go into the LDS image by the bits of the length -- 8, 4, 2, 1
+                    // bytes, unaligned LDS stores (gfx950 takes them) -- four predicated stores instead of sixteen byte
+                    // stores with their extraction
+                    typedef uint32_t __attribute__((aligned(1))) u32_u;
+                    typedef uint16_t __attribute__((aligned(1))) u16_u;
+                    typedef uint64_t __attribute__((aligned(1))) u64_u;
+                    if (src && len < 16u) {       // (not an inline entry: the bytes past the token are somebody else's)
 #pragma unroll
-                    for (uint32_t k = 0; k < 16u; ++k)
-                        if (k < len) {
-                            const uint32_t bk = (w[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
-                            img8[off + k] = (uint8_t)bk;
-                            hi_any |= bk >= 0x80u;
+                        for (uint32_t q = 0; q < 4u; ++q) {
+                            const uint32_t have = len > 4u * q ? len - 4u * q : 0u;
+                            w[q] &= have >= 4u ? 0xFFFFFFFFu : ((1u << (8u * have)) - 1u);
                         }
+                    }
+                    hi_any |= ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0u;
+                    uint8_t* q8 = img8 + off;
+                    uint32_t a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+                    if (len & 16u) {
+                        *reinterpret_cast<u64_u*>(q8) = (uint64_t)a0 | ((uint64_t)a1 << 32);
+                        *reinterpret_cast<u64_u*>(q8 + 8) = (uint64_t)a2 | ((uint64_t)a3 << 32);
+                    }
+                    if (len & 8u) {
+                        *reinterpret_cast<u64_u*>(q8) = (uint64_t)a0 | ((uint64_t)a1 << 32);
+                        a0 = a2; a1 = a3; q8 += 8;
+                    }
+                    if (len & 4u) {
+                        *reinterpret_cast<u32_u*>(q8) = a0;
+                        a0 = a1; q8 += 4;
+                    }
+                    if (len & 2u) {
+                        *reinterpret_cast<u16_u*>(q8) = (uint16_t)a0;
+                        a0 >>= 16; q8 += 2;
+                    }
+                    if (len & 1u) *q8 = (uint8_t)a0;
                 } else {
                     for (uint32_t k = 0; k < len; ++k) {
                         const uint8_t bk = src[k];
@@ -134,10 +217,10 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const uint32_t nwords = (uint32_t)((end - g0 + 3) / 4);
-                for (uint32_t w = (uint32_t)lane; w < nwords; w += 64u) {
-                    const uint64_t ga = g0 + 4ull * w;
+                for (uint32_t wq = (uint32_t)lane; wq < nwords; wq += 64u) {
+                    const uint64_t ga = g0 + 4ull * wq;
                     if (ga >= base && ga + 4 <= end) {
-                        *reinterpret_cast<uint32_t*>(a.out_bytes + ga) = img[w];
+                        *reinterpret_cast<uint32_t*>(a.out_bytes + ga) = img[wq];
                     } else {
                         const uint64_t lo = ga > base ? ga : base, hi = ga + 4 < end ? ga + 4 : end;
                         for (uint64_t q = lo; q < hi; ++q) a.out_bytes[q] = img8[q - g0];
@@ -148,15 +231,16 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
             } else {
                 uint8_t* out = a.out_bytes + dst;  // unusually long tokens: direct byte stores
                 for (uint32_t k = 0; k < len; ++k) {
-                    const uint8_t bk = src[k];
+                    const uint8_t bk = src ? src[k] : (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));   // (no src: an inline entry, <= 15 bytes)
                     out[k] = bk;
                     hi_any |= bk >= 0x80u;
                 }
             }
             cursor = end;
+            id0 = id1; id1 = id2; e0 = e1;
         }
-        const bool doc_hi = __ballot(hi_any) != 0ull;   // ASCII documents need no UTF-8 validation pass
-        if (lane == 0) a.doc_hi[d] = doc_hi ? 1u : 0u;
+        const bool doc_hi = __ballot(hi_any) != 0ull;   // ASCII documents need no UTF-8 validation pass (decided per group)
+        if (dA + (uint64_t)lane < dB) a.doc_hi[dA + lane] = doc_hi ? 1u : 0u;
     }
 }
 
@@ -215,13 +299,15 @@ static uint32_t tkd_doc_grid(uint64_t n_docs) {
 
 hipError_t tk_launch_decode_doclen(const TkDecodeArgs& a, hipStream_t s) {
     if (a.n_docs == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_decode_doclen_kernel, dim3(tkd_doc_grid(a.n_docs)), dim3(TKD_BLOCK), 0, s, a);
+    uint64_t blocks = (a.n_docs + TKD_LEN_BLOCK / 64 - 1) / (TKD_LEN_BLOCK / 64);
+    if (blocks > 256u * 2u) blocks = 256u * 2u;             // every block copies 32 KB into its LDS first: no more than are resident
+    hipLaunchKernelGGL(tk_decode_doclen_kernel, dim3((uint32_t)blocks), dim3(TKD_LEN_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t tk_launch_decode_emit(const TkDecodeArgs& a, hipStream_t s) {
     if (a.n_docs == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_decode_emit_kernel, dim3(tkd_doc_grid(a.n_docs)), dim3(TKD_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(tk_decode_emit_kernel, dim3(tkd_doc_grid((a.n_docs + TKD_DOCS - 1) / TKD_DOCS)), dim3(TKD_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

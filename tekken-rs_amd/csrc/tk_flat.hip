@@ -147,12 +147,16 @@ __global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArg
     const uint64_t wave = (uint64_t)blockIdx.x * (TKM_WIDE_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_WIDE_BLOCK / 64);
     const uint64_t n2 = a.miss_prefix[3 * a.n_chunks] - a.miss_prefix[2 * a.n_chunks];   // pieces of 17..32 bytes: 64 per wave
-    const uint64_t n3 = a.miss_prefix[4 * a.n_chunks] - a.miss_prefix[3 * a.n_chunks];   // pieces of 33..64 bytes: 8 per wave
-    const uint64_t w2 = (n2 + 63) / 64, w3 = (n3 + TKM_LONG3_PER_WAVE - 1) / TKM_LONG3_PER_WAVE;
+    const uint64_t n3 = a.miss_prefix[4 * a.n_chunks] - a.miss_prefix[3 * a.n_chunks];   // pieces of 33..64 bytes: 64 per wave
+    const uint64_t w2 = (n2 + 63) / 64, w3 = (n3 + 63) / 64;
     uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(32);
-    for (uint64_t w = wave; w < w2 + w3; w += n_waves) {
-        if (w < w2) tk_merge_wave<true>(a, w, wv_lane(), mlds, wlds);
-        else tk_merge_wave_long3(a, w - w2, wv_lane(), mlds, wlds);
+    for (uint64_t w = wave; w < w2; w += n_waves) tk_merge_wave<true>(a, w, wv_lane(), mlds, wlds);
+    if (w3 == 0) return;                                     // (grid-uniform)
+    // the class 33..64 bytes needs 64-entry columns: every second wave takes it, with its neighbour's LDS
+    __syncthreads();
+    if (((threadIdx.x >> 6) & 1u) == 0u) {
+        const uint64_t ew = wave >> 1, n_ew = n_waves >> 1;
+        for (uint64_t w = ew; w < w3; w += n_ew) tk_merge_wave_long3(a, w, wv_lane(), mlds, wlds);
     }
 }
 

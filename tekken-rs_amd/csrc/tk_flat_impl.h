@@ -950,18 +950,20 @@ TK_DEV void tk_merge_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint3
     tk_merge_items<WIDE>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
-// The class 33..64 bytes: such a piece is merged by the whole wave (one lane per byte), one piece after the other -- 64 of
-// them in one wave is ~2 ms of a single wave while the rest of the chip idles (white-space runs between line ends on the
-// Zipf shape).  Eight pieces per wave instead; the lane's sub-queue by binary search over the class's prefix sums.
-#define TKM_LONG3_PER_WAVE 8
+// The class 33..64 bytes: 64 pieces per wave, one lane each, in 64-entry LDS columns (tk_merge_lds<64>: 32 KB per wave, so
+// every second wave of the wide kernel takes these, with its neighbour's columns).  The first form merged such a piece
+// with the whole wave, one lane per byte, eight pieces per wave one after the other: fine while the class is rare, but
+// text whose pieces are long by nature (CJK: a run of ideographs between two punctuation marks is ONE \p{L}+ piece of
+// 3 bytes per character) puts most of its bytes here.  The lane's sub-queue by bisection over the class's prefix sums.
+TK_DEV void tk_merge_items64(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* mlds, const uint32_t* filt);
 TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* mlds, const uint32_t* filt) {
     const uint64_t* prefix = a.miss_prefix;
     const uint64_t e0 = 3 * a.n_chunks, e1 = 4 * a.n_chunks;
     const uint64_t first = prefix[e0], total = prefix[e1];
-    const uint64_t item0 = first + wave_id * TKM_LONG3_PER_WAVE;
+    const uint64_t item0 = first + wave_id * 64;
     if (item0 >= total) return;                       // wave-uniform
     const uint64_t item = item0 + (uint64_t)lane;
-    const bool have = lane < TKM_LONG3_PER_WAVE && item < total;
+    const bool have = item < total;
     uint32_t rec = 0;
     uint64_t chunk = 0;
     if (have) {
@@ -973,7 +975,7 @@ TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane,
         chunk = lo - e0;
         rec = a.miss_list[chunk * TKF_MISSCAP + TKF_MISSOFF3 + (item - prefix[lo])];
     }
-    tk_merge_items<true>(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
+    tk_merge_items64(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
 // sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of two
@@ -990,9 +992,22 @@ TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane,
 #else
 #define TKM_AB(a, bit) false
 #endif
+template <int N> struct TkmAlive { typedef uint32_t type; };
+template <> struct TkmAlive<64> { typedef uint64_t type; };
+TK_DEV uint32_t tkm_ctz(uint32_t v) { return (uint32_t)__builtin_ctz(v); }
+TK_DEV uint32_t tkm_ctz(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+TK_DEV uint32_t tkm_msb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+TK_DEV uint32_t tkm_msb(uint64_t v) { return 63u - (uint32_t)__builtin_clzll(v); }
+TK_DEV uint32_t tkm_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+TK_DEV uint32_t tkm_popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+
+// N = 8, 16, 32, 64 (64: the class 33..64 bytes; keys carry six position bits and the live mask is 64 bits wide)
 template <int N>
 TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool mine, const uint32_t* kk, uint32_t len,
                              uint32_t* out, uint32_t* mlds, int lane) {
+    typedef typename TkmAlive<N>::type alive_t;
+    constexpr uint32_t PB = N > 32 ? 6u : 5u, PM = (1u << PB) - 1u;
+    constexpr alive_t ONE = 1;
     const TkTablesView& t = a.t;
     uint32_t* tokc = mlds + lane;
     uint32_t* keyc = mlds + N * 64 + lane;
@@ -1004,12 +1019,12 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
         uint32_t key = 0xFFFFFFFFu;
         if ((uint32_t)(i + 1) < n && !TKM_AB(a, 2048)) {
             const uint32_t r = t.pair2[b | (b1 << 8)];
-            if (r != TK_RANK_MAX) key = (r << 5) | (uint32_t)i;
+            if (r != TK_RANK_MAX) key = (r << PB) | (uint32_t)i;
         }
         tokc[i * 64] = b;
         keyc[i * 64] = key;
     }
-    uint32_t alive = n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    alive_t alive = n >= 8u * (uint32_t)sizeof(alive_t) ? (alive_t)~(alive_t)0 : (alive_t)((ONE << n) - ONE);
     bool active = mine && !TKM_AB(a, 1024);
     while (wv_ballot(active)) {
         if (active) {
@@ -1023,50 +1038,96 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                 active = false;
             } else {
                 // the parts at bi and at the next live position j become one part (at bi) whose id is the rank
-                const uint32_t bi = best & 31u, rank = best >> 5;
-                const uint32_t above = alive & ~((2u << bi) - 1u);            // bi <= N - 2
-                const uint32_t j = (uint32_t)__builtin_ctz(above);            // exists: key[bi] was a pair
-                const uint32_t above2 = above & (above - 1u);
-                const uint32_t below = alive & ((1u << bi) - 1u);
-                const bool has_next = above2 != 0u, has_prev = below != 0u;
-                const uint32_t k = has_next ? (uint32_t)__builtin_ctz(above2) : 0u;
-                const uint32_t p = has_prev ? 31u - (uint32_t)__builtin_clz(below) : 0u;
+                const uint32_t bi = best & PM, rank = best >> PB;
+                const alive_t above = alive & ~(((alive_t)2 << bi) - ONE);   // bi <= N - 2
+                const uint32_t j = tkm_ctz(above);                            // exists: key[bi] was a pair
+                const alive_t above2 = above & (above - ONE);
+                const alive_t below = alive & ((ONE << bi) - ONE);
+                const bool has_next = above2 != 0, has_prev = below != 0;
+                const uint32_t k = has_next ? tkm_ctz(above2) : 0u;
+                const uint32_t p = has_prev ? tkm_msb(below) : 0u;
                 const uint32_t tn = tokc[k * 64], tp = tokc[p * 64];
-                alive &= ~(1u << j);
+                alive &= ~(ONE << j);
                 tokc[bi * 64] = rank;
                 keyc[j * 64] = 0xFFFFFFFFu;
                 uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
                 tk_probe_pair_x2f(t, filt, has_next, rank, tn, has_prev, tp, rank, r_next, r_prev);
-                keyc[bi * 64] = r_next == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_next << 5) | bi);
-                if (has_prev) keyc[p * 64] = r_prev == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_prev << 5) | p);
+                keyc[bi * 64] = r_next == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_next << PB) | bi);
+                if (has_prev) keyc[p * 64] = r_prev == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_prev << PB) | p);
             }
         }
     }
-    const uint32_t np = (uint32_t)__builtin_popcount(alive);
+    const uint32_t np = tkm_popc(alive);
     if (mine && !TKM_AB(a, 256)) {
         // the piece's `len` slots: its np ids, then holes -- gathered into registers and stored four at a time (the cost
         // of a scattered store is per lane and instruction, not per byte), single words only for the last len % 4
-        uint32_t rem = alive;
-        uint32_t v[N];
+        alive_t rem = alive;
 #pragma unroll
-        for (int q = 0; q < N; ++q) {
-            const uint32_t pos = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
-            const uint32_t id = tokc[pos * 64] + t.num_special;
-            v[q] = (uint32_t)q < np ? id : TKF_HOLE;
-            rem &= rem - 1u;
-        }
+        for (int q0 = 0; q0 < N; q0 += 4) {
+            uint32_t v[4];
 #pragma unroll
-        for (int q = 0; q < N; q += 4) {
-            if ((uint32_t)q + 4u <= len) {
-                wv_store16(out + q, v[q], v[q + 1], v[q + 2], v[q + 3]);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t pos = rem ? tkm_ctz(rem) : 0u;
+                const uint32_t id = tokc[pos * 64] + t.num_special;
+                v[q] = (uint32_t)(q0 + q) < np ? id : TKF_HOLE;
+                rem &= rem - ONE;
+            }
+            if ((uint32_t)q0 + 4u <= len) {
+                wv_store16(out + q0, v[0], v[1], v[2], v[3]);
             } else {
-                if ((uint32_t)q < len) out[q] = v[q];
-                if ((uint32_t)q + 1u < len) out[q + 1] = v[q + 1];
-                if ((uint32_t)q + 2u < len) out[q + 2] = v[q + 2];
+                if ((uint32_t)q0 < len) out[q0] = v[0];
+                if ((uint32_t)q0 + 1u < len) out[q0 + 1] = v[1];
+                if ((uint32_t)q0 + 2u < len) out[q0 + 2] = v[2];
             }
         }
     }
     return mine ? len - np : 0u;
+}
+
+// the document of a merged piece loses `holes` ids.  Queued pieces are in text order inside a sub-queue, so neighbouring
+// lanes mostly share their document: the counts of a run of lanes with the same document are summed in the wave (one
+// scan) and its last lane does the one atomic -- 64 atomics on two or three addresses serialise in the L2.
+TK_DEV void tk_merge_holes(const TkFlatArgs& a, bool have, uint32_t holes, uint32_t chunk, int64_t g, int lane) {
+    if (wv_ballot(have && holes != 0u) && !TKM_AB(a, 512)) {
+        // largest d with doc_offs[d] <= g: the documents from first_doc[chunk] - 1 on start at or above the region
+        uint64_t d = 0;
+        if (have) {
+            d = a.first_doc[chunk];
+            d = d > 0 ? d - 1 : 0;
+            while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
+        }
+        const uint32_t key = have ? (uint32_t)d : 0xFFFFFFFFu;             // (documents are numbered below 2^32 - 1)
+        const uint32_t kprev = wv_shfl(key, lane > 0 ? lane - 1 : 0), knext = wv_shfl(key, lane < 63 ? lane + 1 : 63);
+        const bool head = lane == 0 || kprev != key, tail = lane == 63 || knext != key;
+        const uint64_t HEADS = wv_ballot(head);
+        const uint32_t P = wv_scan_incl_u32(have ? holes : 0u);
+        const int start = tk_msb64(HEADS & (tk_lowmask(lane) | (1ull << lane)));      // the head of this lane's run
+        const uint32_t before = wv_shfl(P, start > 0 ? start - 1 : 0);
+        const uint32_t sum = P - (start > 0 ? before : 0u);
+        if (have && tail && sum) wv_atomic_add(a.holes + d, sum);
+    }
+}
+
+// the class 33..64 bytes, one lane per piece like the shorter classes: 64-entry columns (32 KB of LDS per wave)
+TK_DEV void tk_merge_items64(const TkFlatArgs& a, bool have, uint32_t rec, uint32_t chunk, int lane, uint32_t* mlds, const uint32_t* filt) {
+    const uint32_t pos = TKF_REC_POS(rec), len = TKF_REC_LEN(rec), slot = TKF_REC_SLOT(rec);
+    const int64_t g = (int64_t)chunk * TKF_COMMIT - TKF_HL + (int64_t)pos;   // first byte of the piece
+    uint32_t* out = a.tmp + (uint64_t)chunk * TKF_STRIDE + slot;
+    uint32_t kk[16];
+    for (int q = 0; q < 16; ++q) kk[q] = 0u;
+    if (have) {
+        if (g + 64 <= (int64_t)a.n_bytes) {
+            wv_load16(a.bytes + g, kk);
+            wv_load16(a.bytes + g + 16, kk + 4);
+            wv_load16(a.bytes + g + 32, kk + 8);
+            wv_load16(a.bytes + g + 48, kk + 12);
+        } else {
+            for (uint32_t q = 0; q < len; ++q) kk[q >> 2] |= (uint32_t)a.bytes[g + q] << (8 * (q & 3));
+        }
+    }
+    uint32_t holes = 0;
+    if (wv_ballot(have)) holes = tk_merge_lds<64>(a, filt, have, kk, len, out, mlds, lane);
+    tk_merge_holes(a, have, holes, chunk, g, lane);
 }
 
 template <bool WIDE>
@@ -1144,28 +1205,7 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
         if (lane == src) holes = plen - k;
     }
 
-    // ---- the document of the piece loses `holes` ids ---------------------------------------------------
-    // Queued pieces are in text order inside a sub-queue, so neighbouring lanes mostly share their document: the
-    // counts of a run of lanes with the same document are summed in the wave (one scan) and its last lane does the
-    // one atomic -- 64 atomics on two or three addresses serialise in the L2.
-    if (wv_ballot(have && holes != 0u) && !TKM_AB(a, 512)) {
-        // largest d with doc_offs[d] <= g: the documents from first_doc[chunk] - 1 on start at or above the region
-        uint64_t d = 0;
-        if (have) {
-            d = a.first_doc[chunk];
-            d = d > 0 ? d - 1 : 0;
-            while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
-        }
-        const uint32_t key = have ? (uint32_t)d : 0xFFFFFFFFu;             // (documents are numbered below 2^32 - 1)
-        const uint32_t kprev = wv_shfl(key, lane > 0 ? lane - 1 : 0), knext = wv_shfl(key, lane < 63 ? lane + 1 : 63);
-        const bool head = lane == 0 || kprev != key, tail = lane == 63 || knext != key;
-        const uint64_t HEADS = wv_ballot(head);
-        const uint32_t P = wv_scan_incl_u32(have ? holes : 0u);
-        const int start = tk_msb64(HEADS & (tk_lowmask(lane) | (1ull << lane)));      // the head of this lane's run
-        const uint32_t before = wv_shfl(P, start > 0 ? start - 1 : 0);
-        const uint32_t sum = P - (start > 0 ? before : 0u);
-        if (have && tail && sum) wv_atomic_add(a.holes + d, sum);
-    }
+    tk_merge_holes(a, have, holes, chunk, g, lane);
 }
 
 #endif

@@ -72,6 +72,8 @@ struct TkDecodeArgs {
     unsigned long long* err;   // [3] see tk_decode.hip
     const uint8_t* tok_blob;   // token bytes by rank
     const uint32_t* tok_offs;  // [n_ranks + 1]
+    const uint8_t* tok_inline; // [n_ranks] 16-byte entries: the token's bytes (<= 15) and its length in byte 15; 0xFF there = longer, see tok_offs
+    const uint8_t* tok_len8;   // [n_ranks] length of the token, 0xFF = 255 bytes or more (see tok_offs)
     const uint8_t* sp_blob;    // special token strings by POSITION (reference src/tekkenizer.rs:536-540)
     const uint32_t* sp_offs;   // [num_special + 1]
     uint32_t n_ranks, num_special;

@@ -178,10 +178,12 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             if (!guards_ok(TKM_LDS_WORDS(32))) { g_err = "tk_merge_wave<true> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
-        for (uint64_t w = 0; w * TKM_LONG3_PER_WAVE < n_wide3; ++w) {
-            std::fill(mlds.begin(), mlds.end(), 0xDEADBEEFu);
-            tkemu::run_wave([&](int lane) { tk_merge_wave_long3(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
-            if (!guards_ok(TKM_LDS_WORDS(32))) { g_err = "tk_merge_wave_long3 wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
+        std::vector<uint32_t> mlds64(G + TKM_LDS_WORDS(64) + G, 0xDEADBEEFu);
+        for (uint64_t w = 0; w * 64 < n_wide3; ++w) {
+            std::fill(mlds64.begin(), mlds64.end(), 0xDEADBEEFu);
+            tkemu::run_wave([&](int lane) { tk_merge_wave_long3(fa, w, lane, mlds64.data() + G, fa.t.pair_filter); });
+            for (size_t i = 0; i < G; ++i)
+                if (mlds64[i] != 0xDEADBEEFu || mlds64[G + TKM_LDS_WORDS(64) + i] != 0xDEADBEEFu) { g_err = "tk_merge_wave_long3 wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
     }

@@ -619,6 +619,33 @@ def test_sparse_miss_queues(tk, eng_bench, bench_vocab):
     check_batch(eng_bench, orc, data, offs)
 
 
+def test_random_adversarial_vocabularies(tk):
+    """Fresh vocabularies per run of this test (seeded): random multi-byte tokens over tiny alphabets in random rank order --
+    tokens no merge sequence reaches, runs of equal pairs, chains that undercut -- and random texts over the same alphabets
+    with pieces of every length class (2..8, 9..16, 17..32, 33..64 in the merge kernels' LDS columns, longer ones in pass 2,
+    the longest through the round-based workgroup merges).  The HIP path against the oracle, id for id."""
+    import random
+    import gen_golden_merge as gg
+    rng = random.Random(20260917)
+    # (n_extra stays below the number of strings the alphabet can make: the generator draws until it has that many)
+    for alphabet, n_extra, max_len in (("ab", 60, 6), ("abc", 250, 5), ("abcd ", 1500, 7), ("aé中", 90, 4), ("xyz'\n", 900, 9)):
+        toks = gg.vocab_adversarial(rng, alphabet, n_extra, max_len)
+        v = {"tokens": toks, "num_special": 7, "bos": 1, "eos": 2}
+        eng = tk.Engine(toks, 7, 1, 2, device=0)
+        orc = helpers.oracle_for(v)
+        letters = [c for c in alphabet if c not in " '\n"]
+        docs = []
+        for n in list(range(1, 70)) + [80, 100, 130, 200, 513, 1500, 5000]:
+            for _ in range(3 if n < 70 else 1):
+                docs.append("".join(rng.choice(letters) for _ in range(n)).encode())            # one piece
+                docs.append("".join(rng.choice(alphabet) for _ in range(n)).encode())           # whatever the split makes of it
+        docs.append(("".join(rng.choice(letters) for _ in range(40)) + " ").encode() * 300)      # many class-3 pieces in one document
+        data, offs = tk.pack_docs(docs)
+        check_batch(eng, orc, data, offs)
+        check_batch(eng, orc, data, offs, False, False)
+        eng.close()
+
+
 def test_small_batches_one_launch(tk, test_vocab, bench_vocab):
     """tk_encode_one and small tk_encode_batch calls (<= 1024 documents, <= 64 KiB) run as ONE launch (tk_small_kernel);
     ids identical to the oracle, a document that needs pass 2 falls back,

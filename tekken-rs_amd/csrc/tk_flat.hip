@@ -274,19 +274,30 @@ __device__ __forceinline__ void tkf_assemble_doc(const TkFlatAssembleArgs& a, co
     uint32_t left = di.n_slots, nn = di.n_first;
     uint64_t c = di.src >> 32;
     const uint32_t* src = a.tmp + c * TKF_STRIDE + (uint32_t)di.src;
+    // four groups of 64 slots are requested together (a long document is a chain of load -> ballot -> store steps: one
+    // group at a time leaves the wave waiting a memory round trip per 64 ids), and the next row's slot count with them
+    const uint64_t below = (1ull << lane) - 1ull;
     while (left) {
-        for (uint32_t k0 = 0; k0 < nn; k0 += 64u) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            const uint32_t v = k < nn ? src[k] : TKF_HOLE;
-            const uint64_t keep = __ballot(v != TKF_HOLE);
-            if (v != TKF_HOLE) dst[__builtin_popcountll(keep & ((1ull << lane) - 1ull))] = v;
-            dst += __builtin_popcountll(keep);
+        uint32_t kc_next = 0;
+        if (left > nn) kc_next = a.kcount[c + 1];
+        for (uint32_t k0 = 0; k0 < nn; k0 += 256u) {
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t k = k0 + 64u * (uint32_t)q + (uint32_t)lane;
+                v[q] = k < nn ? src[k] : TKF_HOLE;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t keep = __ballot(v[q] != TKF_HOLE);
+                if (v[q] != TKF_HOLE) dst[__builtin_popcountll(keep & below)] = v[q];
+                dst += __builtin_popcountll(keep);
+            }
         }
         left -= nn;
         if (left == 0) break;
         ++c;
-        const uint32_t kc = a.kcount[c];
-        nn = left < kc ? left : kc;
+        nn = left < kc_next ? left : kc_next;
         src = a.tmp + c * TKF_STRIDE;
     }
     if (a.add_eos && lane == 0) dst[0] = a.eos_id;

@@ -117,6 +117,7 @@ struct tk_ctx {
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
     DevBuf t_inline, t_len8;   // decode: 16-byte inline entries and one-byte lengths by rank (built at the first decode call)
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
+    DevBuf f_long;             // flat path: records of the pieces of 65..TKF_LONGCAP bytes
     DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
     DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
     uint32_t long_min = 1024;      // shortest piece (bytes) merged in rounds by a workgroup (TK_LONG_MIN; 0 = never)
@@ -126,6 +127,8 @@ struct tk_ctx {
     bool use_flat = true;
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
+    uint64_t n_long_recs = 0;      // pieces of 65..TKF_LONGCAP bytes the flat path kept (last call)
+    bool no_flat_long = false;     // TK_FLAT_LONG=0: such pieces hand their documents back (the round-1 behaviour; A / B and tests)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
     uint64_t n_long_docs = 0;
@@ -248,6 +251,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         c->err = "wave primitive self-test failed on this device (mask " + std::to_string(bad) + ")";
         return fail(TK_ERR_RUNTIME);
     }
+    if (const char* fl = getenv("TK_FLAT_LONG")) c->no_flat_long = atoi(fl) == 0;
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
     if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
@@ -263,7 +267,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->t_inline, &c->t_len8,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
-                      &c->scratch, &c->long_list, &c->long_jobs, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
+                      &c->scratch, &c->long_list, &c->long_jobs, &c->f_long, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
@@ -486,6 +490,14 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.t = c->dview;
     fa.pattern = c->pattern;
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
+    // pieces of 65..TKF_LONGCAP bytes stay on the flat path as records (counter 11); TK_FLAT_LONG=0: they hand their documents back
+    const uint64_t long_cap = n_bytes / 65 + 1024;
+    if (!c->no_flat_long) {
+        TK_HIP(c, c->f_long.reserve(long_cap * sizeof(TkFlatLongRec)));
+        fa.long_recs = (TkFlatLongRec*)c->f_long.p;
+        fa.long_count = (uint32_t*)c->counters.p + 11;
+        fa.long_cap = (uint32_t)(long_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : long_cap);
+    }
 
     // One host sync per batch in the common case.  Everything that depends on device-side counts stays on the device:
     // the merge kernels are persistent, the output buffer takes its upper bound (a document cannot produce more ids
@@ -513,7 +525,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_merge(fa, s));
     uint64_t total = 0;
-    uint32_t n_todo = 0;
+    uint32_t n_todo = 0, n_lrec = 0;
     auto finish = [&](int final_pass) -> int {
         TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, d_P, fa.lstart, fa.flags, fa.holes, extra,
                                         (uint32_t*)c->counts.p, c->f_info.p, final_pass, (uint32_t*)c->counters.p + 4, s));
@@ -523,11 +535,12 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
                                           c->host.eos_id, add_bos, add_eos, (uint64_t*)((uint32_t*)c->counters.p + 6),
                                           final_pass ? nullptr : (const uint32_t*)c->counters.p + 4, s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
-        // counters 4 (handed-back documents) and 6..7 (total ids, left there by the assembly): one copy into pinned memory
-        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 32, hipMemcpyDeviceToHost, s));
+        // counters 4 (handed-back documents), 6..7 (total ids, left there by the assembly) and 11 (long-piece records): one
+        // copy into pinned memory
+        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 48, hipMemcpyDeviceToHost, s));
         TK_HIP(c, hipStreamSynchronize(s));
         memcpy(&total, c->h_pin + 6, 8);
-        if (!final_pass) n_todo = c->h_pin[4];
+        if (!final_pass) { n_todo = c->h_pin[4]; n_lrec = c->h_pin[11]; }
         return TK_OK;
     };
     int rc = finish(0);
@@ -536,12 +549,32 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     c->n_long_docs = 0;
     if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,
                      (unsigned long long)n_chunks, n_todo);
-    if (n_todo) {
-        // the per-document path over the handed-back documents: pass 1 (mode 3), then pass 2 for its own deferrals
+    if (n_lrec) {
+        // the long-piece records: one wave each (lookup / single-wave merge into the reserved slots); a piece that turns out
+        // longer than TKF_LONGCAP flags its document, so the handed-back documents are counted again afterwards
+        if (n_lrec > fa.long_cap) n_lrec = fa.long_cap;
+        c->n_long_recs = n_lrec;
+        const uint32_t lwaves = ((n_lrec < 8192u ? n_lrec : 8192u) + 3u) / 4u * 4u;
+        TK_HIP(c, c->scratch.reserve((size_t)lwaves * TKF_LONG_SCRATCH_WORDS * 4));
+        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
+        TK_HIP(c, tk_launch_flat_long(fa, (uint32_t*)c->counters.p, (uint32_t*)c->scratch.p, TKF_LONG_SCRATCH_WORDS, lwaves, s));
+    } else {
+        c->n_long_recs = 0;
+    }
+    if (n_todo || n_lrec) {
         TK_HIP(c, c->staging.reserve((n_bytes + 2 * n_docs + 64) * 4));
         TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
         TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 4, 0, 4, s));
         TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
+        if (n_lrec) {
+            TK_HIP(c, hipMemcpyAsync(c->h_pin + 4, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
+            TK_HIP(c, hipStreamSynchronize(s));
+            n_todo = c->h_pin[4];
+            c->n_flagged = n_todo;
+        }
+    }
+    if (n_todo) {
+        // the per-document path over the handed-back documents: pass 1 (mode 3), then pass 2 for its own deferrals
         TkEncodeArgs a;
         memset(&a, 0, sizeof(a));
         a.bytes = d_bytes;
@@ -577,6 +610,10 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
                 if (rc2 != TK_OK) return rc2;
             }
         }
+    }
+    if (n_todo || n_lrec) {
+        // (the long kernel has zeroed nothing the final pass reads: counter 11 still holds the record count, and the final
+        // assembly does not look at it)
         rc = finish(1);
         if (rc != TK_OK) return rc;
     }

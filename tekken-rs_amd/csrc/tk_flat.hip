@@ -252,7 +252,8 @@ struct TkFlatAssembleArgs {
     uint32_t bos_id, eos_id;
     int add_bos, add_eos;
     uint64_t* total_out;      // receives out_offs[n_docs] (the host reads it with the other counters)
-    const uint32_t* skip_if;  // optimistic first pass: nothing is copied when *skip_if != 0 (documents were handed back: the host
+    const uint32_t* skip_if;  // optimistic first pass (counters + 4): nothing is copied when skip_if[0] != 0 (documents were handed back)
+                              // or skip_if[7] != 0 (long-piece records wait for tk_flat_long_kernel): the host
                               // runs the per-document kernels and assembles again); NULL for the final pass
 };
 
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_assemble_kernel(TkFlatAssem
     const uint64_t wave = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
     if (wave == 0 && lane == 0) *a.total_out = a.out_offs[a.n_docs];
-    if (a.skip_if && *a.skip_if != 0u) return;               // (grid-uniform)
+    if (a.skip_if && (a.skip_if[0] != 0u || a.skip_if[7] != 0u)) return;   // (grid-uniform; counters 4 and 11)
     for (uint64_t d0 = wave * 64; d0 < a.n_docs; d0 += n_waves * 64) {
         const uint64_t dm = d0 + (uint64_t)lane;
         TkFlatDocInfo mine;
@@ -451,6 +452,29 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
                        a.n_chunks, a.wave_first, a.wave_first_wide);
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKM_BLOCK), TKM_LDS_BYTES, s, a);
     hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKM_WIDE_BLOCK), TKM_WIDE_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+// Pieces of 65..TKF_LONGCAP bytes (tk_flat_impl.h step 6): one wave per record -- the end of the piece where the chunk did
+// not see it (sequential matcher), whole-piece lookup, the single-wave merge; ids + holes into the slots the chunk
+// reserved, the document's hole count like the merge kernels.  Launched only when the flat kernel wrote records.
+__global__ __launch_bounds__(256) void tk_flat_long_kernel(TkFlatArgs a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words) {
+    const int lane = wv_lane();
+    const TkPolyPow pw = tk_poly_pow(a.t, lane);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t* my = scratch + wave_id * scratch_words;
+    const uint32_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    for (;;) {
+        const uint32_t ticket = wv_first(wv_atomic_add_all(work_counter, 1u));   // (all lanes take part: DESIGN.md 4.7)
+        const uint32_t q = ticket / 64u;
+        if (q >= n) break;
+        tk_flat_long_wave(a, pw, q, lane, my);
+    }
+}
+
+hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words, uint32_t n_waves,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(tk_flat_long_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, s, a, work_counter, scratch, scratch_words);
     return hipGetLastError();
 }
 

@@ -12,7 +12,9 @@
 #define TKF_HL 32                                    /* left halo (look-behind context) */
 #define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
 #define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* bytes committed per chunk: 928 / 1952 */
-#define TKF_STRIDE (TKF_COMMIT + 64)                 /* id slots per chunk: a piece may reach 63 bytes past the commit range */
+#define TKF_LONGCAP 256u                             /* a piece of 65..LONGCAP bytes keeps its document on the flat path (tk_flat_long_kernel) */
+#define TKF_STRIDE (TKF_COMMIT + 64 + TKF_LONGCAP)   /* id slots per chunk: a piece may reach 63 bytes past the commit range, and the
+                                                        chunk's last piece, when its end is not in the region, reserves LONGCAP slots */
 /* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes) */
 #define TKF_MISSOFF0 0u
 #define TKF_MISSOFF1 (TKF_COMMIT / 2u)                              /* at most COMMIT / 2 pieces of >= 2 bytes */
@@ -31,6 +33,15 @@
 #define TKF_REC_SLOT(rec) ((rec) >> (TKF_POSBITS + 7))
 #define TKF_HOLE 0xFFFFFFFFu                         /* id slot reserved by a missed piece and not used */
 
+// a piece of more than 64 bytes that the flat kernel leaves to tk_flat_long_kernel (one wave per record)
+struct TkFlatLongRec {
+    uint64_t pos;        // first byte of the piece in the packed stream
+    uint32_t chunk;      // owning chunk: its ids go to tmp[chunk * TKF_STRIDE + slot ..]
+    uint32_t slot;
+    uint32_t len;        // bytes of the piece; 0: the end lies beyond the chunk's region (the sequential matcher finds it)
+    uint32_t reserved;   // id slots reserved for it: len, or TKF_LONGCAP when the end was not seen
+};
+
 struct TkFlatArgs {
     const uint8_t* bytes;        // packed text of all documents
     const uint64_t* doc_offs;    // [n_docs + 1]
@@ -47,6 +58,9 @@ struct TkFlatArgs {
     uint32_t* wave_first_wide;   // [wide items / 64 + 1] the same for the wide classes (items counted from the first wide one)
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
+    TkFlatLongRec* long_recs;    // [long_cap] pieces of 65..TKF_LONGCAP bytes (NULL: such a piece hands its document back)
+    uint32_t* long_count;        // records appended (may exceed long_cap: the surplus pieces hand their documents back)
+    uint32_t long_cap;
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
     int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,

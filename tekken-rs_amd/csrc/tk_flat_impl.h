@@ -772,9 +772,17 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
         bool toolong = false;
-        if (wv_ballot(len > 16u)) {                         // rare: polynomial hash over the bytes, LONG table; > 64: hand back
+        uint32_t lres = 0;                                  // a long piece that stays on the flat path: id slots reserved for it
+        bool lopen = false;
+        if (wv_ballot(len > 16u)) {                         // rare: polynomial hash over the bytes, LONG table; > 64: see below
             if (len > 64u) {
-                toolong = true;
+                // More than 64 bytes.  Up to TKF_LONGCAP the piece is left to tk_flat_long_kernel (whole-piece lookup, merge)
+                // and the document stays here: `len` slots are reserved like for any missed piece.  The chunk's LAST piece
+                // may end beyond the region (its length here is only "up to the region end"): it reserves LONGCAP slots and
+                // the long kernel finds the end with the sequential matcher -- beyond LONGCAP it flags the document itself.
+                lopen = idx + 1u == np_all && sentinel == TKF_REGION && r0 + (int64_t)TKF_REGION < (int64_t)a.n_bytes;
+                if (!PAT && a.long_recs != nullptr && (lopen || len <= TKF_LONGCAP)) lres = lopen ? TKF_LONGCAP : len;
+                else toolong = true;
             } else if (len > 16u && !(DBG && (a.dbg_ablate & 1))) {
                 uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
                 for (uint32_t q = 0; q < len; ++q) {
@@ -787,10 +795,39 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
         }
         // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
-        const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
+        const bool longp = lres != 0u;
+        const bool miss = r == TK_RANK_MAX && !toolong && !longp && !(DBG && (a.dbg_ablate & 2));
         uint32_t slot = base_own + idx + E;
         const uint64_t MB = wv_ballot(miss);
-        if (MB) {
+        if (wv_ballot(longp)) {                             // rare
+            uint32_t tot;
+            slot += tkf_scan_excl(miss ? len - 1u : longp ? lres - 1u : 0u, lane, &tot);
+            E += tot;
+            if (longp) {
+                const uint32_t q = wv_atomic_add(a.long_count, 1u);
+                if (q < a.long_cap) {
+                    TkFlatLongRec lr;
+                    lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = slot; lr.len = lopen ? 0u : len; lr.reserved = lres;
+                    a.long_recs[q] = lr;
+                } else {                                    // no room for the record: the document is handed back after all
+                    wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
+                }
+            }
+            if (MB) {                                       // the misses of the batch: queued by class (the general form below)
+                const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
+                const uint32_t sh = cls * 8u;
+                uint32_t ctot;
+                const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
+                if (miss) {
+                    const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
+                    mq[qb + before] = TKF_REC(pos, len, slot);
+                }
+                nm0 += ctot & 0xFFu;
+                nm1 += (ctot >> 8) & 0xFFu;
+                nm2 += (ctot >> 16) & 0xFFu;
+                nm3 += ctot >> 24;
+            }
+        } else if (MB) {
             // A miss reserves `len` id slots (it cannot produce more ids than bytes): one per piece + (len - 1) more for
             // every miss before it.  The misses are queued in the chunk's own region (no global atomics), records in
             // piece order, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one
@@ -828,7 +865,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
             list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
-            if (!miss && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
+            if (!miss && !longp && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
         }
     }
     if (pass + 1 < npass) {
@@ -858,6 +895,46 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     wv_lds_sync();
     doc_outputs(true, anybad);
     wv_lds_sync();  // the next chunk reuses the LDS slice
+}
+
+// ------------------------------------------------------------------------------------------
+// One long-piece record (step 6 above), by one wave: what the per-document kernels would do with this piece, but
+// only with this piece -- the rest of its document stays on the flat path.
+// ------------------------------------------------------------------------------------------
+TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t q, int lane, uint32_t* scratch) {
+    const TkFlatLongRec lr = a.long_recs[q];
+    const uint64_t g = lr.pos;
+    // the piece's document: largest d with doc_offs[d] <= g
+    uint64_t d = a.first_doc[lr.chunk];
+    d = d > 0 ? d - 1 : 0;
+    while (d + 1 < a.n_docs && a.doc_offs[d + 1] <= g) ++d;
+    d = wv_first64(d);
+    if (wv_first(a.flags[d]) != 0u) return;                 // handed back anyway: its slots are never read
+    TkEncodeArgs ea;
+    ea.bytes = a.bytes; ea.doc_offs = a.doc_offs; ea.n_docs = a.n_docs; ea.staging = nullptr; ea.counts = nullptr;
+    ea.work_counter = nullptr; ea.defer_count = nullptr; ea.defer_list = nullptr; ea.todo_list = nullptr; ea.n_todo = 0;
+    ea.scratch = scratch; ea.scratch_words_per_wave = 0; ea.add_bos = 0; ea.add_eos = 0; ea.split_only = 0; ea.pattern = 0; ea.dbg_ablate = 0;
+    ea.dbg_starts = nullptr; ea.dbg_mark = nullptr; ea.long_list = nullptr; ea.long_count = nullptr; ea.long_min = 0; ea.long_force = 0;
+    ea.long_jobs = nullptr; ea.long_job_count = nullptr; ea.long_job_cap = 0; ea.t = a.t;
+    const uint64_t s1 = wv_first64(a.doc_offs[d + 1]);
+    const uint64_t e = lr.len ? g + lr.len : wv_first64(tk_match_end(a.t, a.bytes, g, s1));
+    const uint32_t len = (uint32_t)(e - g);
+    uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;
+    if (e - g > (uint64_t)lr.reserved) {                    // an open piece of more than LONGCAP bytes: the per-document kernels take the document
+        if (lane == 0) a.flags[d] = 1u;
+        return;
+    }
+    uint32_t cur = 0;
+    const uint32_t r = tk_piece_lookup(ea, pw, lane, g, e);
+    if (r != TK_RANK_MAX) {
+        if (lane == 0) out[0] = r + a.t.num_special;
+        cur = 1;
+    } else {
+        tk_piece_merge_coop(ea, lane, g, e, out, cur, scratch);
+    }
+    (void)len;
+    for (uint32_t k = cur + (uint32_t)lane; k < lr.reserved; k += 64u) out[k] = TKF_HOLE;
+    if (lane == 0) wv_atomic_add(a.holes + d, lr.reserved - cur);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,6 +42,10 @@ hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, ui
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
                                    uint32_t* flags, uint32_t* holes, uint32_t* counters16, hipStream_t s);
 hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
+// the long-piece records of the flat kernel (65..TKF_LONGCAP bytes): n_waves persistent waves, scratch_words words of scratch each
+#define TKF_LONG_SCRATCH_WORDS 2048u
+hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words, uint32_t n_waves,
+                               hipStream_t s);
 hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
 // doc_info: [n_docs] 16-byte records (TkFlatDocInfo, tk_flat.hip) written by counts, read by assemble
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,

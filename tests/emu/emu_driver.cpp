@@ -95,6 +95,9 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
 // Flat path on the emulator: tk_flat_chunk for every chunk (one emulated wave), the flagged documents through
 // the per-document algorithm (mode 3, then pass 2), and host restatements of the small bookkeeping kernels of
 // tk_flat.hip (first_doc, todo list, chunk prefix sums, counts, assemble).
+#ifndef TKF_LONG_SCRATCH_WORDS
+#define TKF_LONG_SCRATCH_WORDS 2048u
+#endif
 extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special,
                                      uint32_t bos, uint32_t eos, const uint8_t* bytes, const uint64_t* doc_offs,
                                      uint64_t n_docs, int add_bos, int add_eos, uint32_t* out_ids, uint64_t* out_offs,
@@ -131,6 +134,14 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.dbg_starts = dbg_starts;
     fa.pattern = pattern;
     fa.t = T.host_view();
+    // pieces of 65..TKF_LONGCAP bytes stay on the flat path as records (TK_FLAT_LONG=0: they hand their documents back)
+    std::vector<TkFlatLongRec> long_recs(n_bytes / 65 + 16);
+    uint32_t long_count = 0;
+    if (!(getenv("TK_FLAT_LONG") && atoi(getenv("TK_FLAT_LONG")) == 0)) {
+        fa.long_recs = long_recs.data();
+        fa.long_count = &long_count;
+        fa.long_cap = (uint32_t)long_recs.size();
+    }
     std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
     uint64_t ops = 0;
     if (n_chunks) {
@@ -185,6 +196,20 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             for (size_t i = 0; i < G; ++i)
                 if (mlds64[i] != 0xDEADBEEFu || mlds64[G + TKM_LDS_WORDS(64) + i] != 0xDEADBEEFu) { g_err = "tk_merge_wave_long3 wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
+        }
+    }
+    // the long-piece records (tk_flat_long_kernel): one wave each; a piece beyond TKF_LONGCAP flags its document
+    {
+        std::vector<uint32_t> lscratch(TKF_LONG_SCRATCH_WORDS + 64, 0xDEADBEEFu);
+        const uint32_t nl = long_count < fa.long_cap ? long_count : fa.long_cap;
+        for (uint32_t q = 0; q < nl; ++q) {
+            tkemu::run_wave([&](int lane) {
+                const TkPolyPow pw = tk_poly_pow(fa.t, lane);
+                tk_flat_long_wave(fa, pw, q, lane, lscratch.data());
+            });
+            ops += tkemu::g_wave->n_ops;
+            for (size_t i = 0; i < 64; ++i)
+                if (lscratch[TKF_LONG_SCRATCH_WORDS + i] != 0xDEADBEEFu) { g_err = "tk_flat_long_wave wrote past its scratch"; return TK_ERR_RUNTIME; }
         }
     }
     // flagged documents -> per-document algorithm

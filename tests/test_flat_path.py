@@ -87,6 +87,36 @@ def test_emu_flat_sparse_miss_queues(test_vocab):
     assert _emu_check(test_vocab, docs) == []
 
 
+def test_emu_flat_long_pieces_stay_on_the_flat_path(test_vocab):
+    """Pieces of 65..256 bytes (tk_flat_impl.h step 6, tk_flat_long_wave): their documents are NOT handed back -- the piece
+    becomes a record, its ids come from one wave's lookup / merge into the reserved slots; where the chunk does not see the
+    end of its last piece (the piece crosses the region end) the sequential matcher finds it; beyond 256 bytes the document
+    is handed back after all.  Letter runs, CJK runs, punctuation runs, at every offset around a chunk boundary."""
+    import random
+    rng = random.Random(5)
+    filler = b"ab cd ef gh ij kl mn op qr st uv wx yz " * 60                 # 2340 bytes of short pieces
+    kept, handed = [], []
+    for n in (64, 65, 100, 128, 200, 254, 255):                               # (the blank in front belongs to the piece: n + 1 bytes)
+        w = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(n)).encode()
+        kept.append(b"x " + w + b" y")
+        kept.append(filler[:1899] + w + b" " + filler[:300])                  # crosses the end of the first chunk's region or not
+    for k in range(1880, 2030, 7):                                            # the piece's first byte walks over the chunk boundary
+        w = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(150)).encode()
+        kept.append(filler[:k] + b" " + w + b" " + filler[:200])
+    kept.append(("中" * 30 + "，" + "文" * 60 + "。" + "字" * 80).encode())          # 93- / 183- / 243-byte pieces
+    kept.append(b"head " + b"=" * 200 + b"\n\ntail")
+    kept.append((" " + "é" * 100 + " x").encode())
+    for n in (256, 300, 1000):
+        w = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(n)).encode()
+        handed.append(b"x " + w + b" y")
+        handed.append(filler[:1899] + w + b" z")
+    docs = kept + handed
+    flagged = _emu_check(test_vocab, docs)
+    assert set(flagged) == set(range(len(kept), len(docs))), flagged
+    for bos, eos in ((False, False), (True, False)):
+        _emu_check(test_vocab, docs, bos, eos)
+
+
 def test_emu_flat_handback_and_mixed(test_vocab):
     docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120)
     flagged = _emu_check(test_vocab, docs)

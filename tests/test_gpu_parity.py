@@ -619,6 +619,49 @@ def test_sparse_miss_queues(tk, eng_bench, bench_vocab):
     check_batch(eng_bench, orc, data, offs)
 
 
+def test_long_pieces_stay_on_the_flat_path(tk, eng_small, eng_bench, test_vocab, bench_vocab, monkeypatch):
+    """Pieces of 65..256 bytes (csrc/tk_flat_impl.h step 6, tk_flat_long_kernel): their documents are not handed back; beyond 256
+    bytes they are.  Letter runs, CJK paragraphs, rulers, the first byte of the piece walking over a chunk boundary, many
+    such pieces per document; the same batch with the path switched off (TK_FLAT_LONG=0) gives the same ids."""
+    import random
+    rng = random.Random(5)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    filler = b"ab cd ef gh ij kl mn op qr st uv wx yz " * 60
+    kept, handed = [], []
+    for n in (64, 65, 100, 128, 200, 254, 255):
+        w = "".join(rng.choice(letters) for _ in range(n)).encode()
+        kept.append(b"x " + w + b" y")
+        kept.append(filler[:1899] + w + b" " + filler[:300])
+    for k in range(1880, 2030, 3):
+        w = "".join(rng.choice(letters) for _ in range(150)).encode()
+        kept.append(filler[:k] + b" " + w + b" " + filler[:200])
+    ideo = [chr(0x4E00 + rng.randrange(0x5000)) for _ in range(500)]
+    for _ in range(300):
+        parts = []
+        while sum(len(x) for x in parts) < 700:
+            parts.append("".join(rng.choice(ideo) for _ in range(rng.randint(5, 80))) + rng.choice("，。"))
+        kept.append("".join(parts).encode())
+    kept.append(b"head " + b"=" * 200 + b"\n\ntail")
+    kept.append((" " + "é" * 100 + " x").encode())
+    for n in (256, 300, 1000):
+        w = "".join(rng.choice(letters) for _ in range(n)).encode()
+        handed.append(b"x " + w + b" y")
+        handed.append(filler[:1899] + w + b" z")
+    docs = kept + handed
+    data, offs = tk.pack_docs(docs)
+    for eng, v in ((eng_small, test_vocab), (eng_bench, bench_vocab)):
+        orc = helpers.oracle_for(v)
+        ids, oo = check_batch(eng, orc, data, offs)
+        assert eng.last_stats()["handed_back"] == len(handed)
+        check_batch(eng, orc, data, offs, False, False)
+    monkeypatch.setenv("TK_FLAT_LONG", "0")
+    e0 = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
+    ids0, oo0 = e0.encode_batch(data, offs, True, True)
+    assert e0.last_stats()["handed_back"] > len(handed)
+    assert np.array_equal(ids0, ids) and np.array_equal(oo0, oo)
+    e0.close()
+
+
 def test_random_adversarial_vocabularies(tk):
     """Fresh vocabularies per run of this test (seeded): random multi-byte tokens over tiny alphabets in random rank order --
     tokens no merge sequence reaches, runs of equal pairs, chains that undercut -- and random texts over the same alphabets
@@ -741,7 +784,9 @@ def test_long_pieces_merged_in_rounds(tk, test_vocab, bench_vocab, monkeypatch):
                 assert e.round_path_docs() >= 10
             e.close()
     # the adversarial merge vocabularies (pairs that undercut): pieces of 65 .. 200 bytes through the round-based kernel
+    # (TK_FLAT_LONG=0: such pieces hand their documents back instead of staying on the flat path as records)
     monkeypatch.setenv("TK_LONG_MIN", "65")
+    monkeypatch.setenv("TK_FLAT_LONG", "0")
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "merge_vectors.json")) as f:
         g = json.load(f)
     took = 0

@@ -128,6 +128,8 @@ struct tk_ctx {
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
     uint64_t n_long_recs = 0;      // pieces of 65..TKF_LONGCAP bytes the flat path kept (last call)
+    void* long_ctl_ptr = nullptr;  // what the control words at counters + 16 describe
+    uint32_t long_ctl_cap = 0;
     bool no_flat_long = false;     // TK_FLAT_LONG=0: such pieces hand their documents back (the round-1 behaviour; A / B and tests)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -237,7 +239,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview.pair_filter = (const uint32_t*)c->t_pairf.p;
     c->dview.blob = (const uint8_t*)c->t_blob.p;
 
-    if (c->counters.reserve(64) != hipSuccess) { c->err = "hipMalloc(counters) failed"; return fail(TK_ERR_RUNTIME); }
+    if (c->counters.reserve(128) != hipSuccess) { c->err = "hipMalloc(counters) failed"; return fail(TK_ERR_RUNTIME); }
     // the wave primitives (DPP wave shifts, bpermute) are checked once on the real device
     uint32_t bad = 1;
     if (hipMemsetAsync(c->counters.p, 0, 64, c->stream) != hipSuccess ||
@@ -496,7 +498,18 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, c->f_long.reserve(long_cap * sizeof(TkFlatLongRec)));
         fa.long_recs = (TkFlatLongRec*)c->f_long.p;
         fa.long_count = (uint32_t*)c->counters.p + 11;
-        fa.long_cap = (uint32_t)(long_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : long_cap);
+        fa.long_cap = (uint32_t)(c->f_long.cap / sizeof(TkFlatLongRec) > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : c->f_long.cap / sizeof(TkFlatLongRec));
+        fa.long_ctl = (const uint32_t*)c->counters.p + 16;
+        // the control words behind the counters (not touched by the pre-pass, which clears words 0..15): written when the
+        // record buffer changes, i.e. a handful of times in a context's life
+        if (c->long_ctl_ptr != c->f_long.p || c->long_ctl_cap != fa.long_cap) {
+            const uint64_t pv = (uint64_t)reinterpret_cast<uintptr_t>(c->f_long.p);
+            const uint32_t ctl[3] = {(uint32_t)pv, (uint32_t)(pv >> 32), fa.long_cap};
+            TK_HIP(c, hipMemcpyAsync((uint32_t*)c->counters.p + 16, ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
+            TK_HIP(c, hipStreamSynchronize(s));
+            c->long_ctl_ptr = c->f_long.p;
+            c->long_ctl_cap = fa.long_cap;
+        }
     }
 
     // One host sync per batch in the common case.  Everything that depends on device-side counts stays on the device:

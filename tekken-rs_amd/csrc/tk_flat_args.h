@@ -58,9 +58,13 @@ struct TkFlatArgs {
     uint32_t* wave_first_wide;   // [wide items / 64 + 1] the same for the wide classes (items counted from the first wide one)
     uint32_t* holes;             // [n_docs] reserved id slots the document's missed pieces did not use
     uint32_t* flags;             // [n_docs] 1 = the document is redone by the per-document kernel
-    TkFlatLongRec* long_recs;    // [long_cap] pieces of 65..TKF_LONGCAP bytes (NULL: such a piece hands its document back)
+    TkFlatLongRec* long_recs;    // [long_cap] pieces of 65..TKF_LONGCAP bytes (what tk_flat_long_kernel reads)
     uint32_t* long_count;        // records appended (may exceed long_cap: the surplus pieces hand their documents back)
     uint32_t long_cap;
+    const uint32_t* long_ctl;    // what the flat kernel reads, in its rare path only, so that the three values above cost it no
+                                 // scalar registers: device words {long_recs lo, hi, long_cap}, the record counter five words
+                                 // BELOW them (the context's counter block: counter 11, control words at 16..18).  NULL: a piece
+                                 // of more than 64 bytes hands its document back
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
     int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,

@@ -423,6 +423,8 @@ TK_DEV void tk_flat_init_lds(const TkFlatArgs& a, uint32_t* lds, int lane) {
         lds[TKF_L_CONST + 1] = a.t.key_mask;
         lds[TKF_L_CONST + 2] = (uint32_t)b8; lds[TKF_L_CONST + 3] = (uint32_t)(b8 >> 32);
         lds[TKF_L_CONST + 4] = (uint32_t)b16; lds[TKF_L_CONST + 5] = (uint32_t)(b16 >> 32);
+        const uint64_t lc = (uint64_t)reinterpret_cast<uintptr_t>(a.long_ctl);
+        lds[TKF_L_CONST + 6] = (uint32_t)lc; lds[TKF_L_CONST + 7] = (uint32_t)(lc >> 32);
     }
     if (lane <= 16) {
         for (int q = 0; q < 4; ++q) {
@@ -772,16 +774,17 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
         bool toolong = false;
-        uint32_t lres = 0;                                  // a long piece that stays on the flat path: id slots reserved for it
-        bool lopen = false;
         if (wv_ballot(len > 16u)) {                         // rare: polynomial hash over the bytes, LONG table; > 64: see below
+            uint32_t lres = 0;                              // a long piece that stays on the flat path: id slots reserved for it
+            bool lopen = false;
             if (len > 64u) {
                 // More than 64 bytes.  Up to TKF_LONGCAP the piece is left to tk_flat_long_kernel (whole-piece lookup, merge)
                 // and the document stays here: `len` slots are reserved like for any missed piece.  The chunk's LAST piece
                 // may end beyond the region (its length here is only "up to the region end"): it reserves LONGCAP slots and
                 // the long kernel finds the end with the sequential matcher -- beyond LONGCAP it flags the document itself.
                 lopen = idx + 1u == np_all && sentinel == TKF_REGION && r0 + (int64_t)TKF_REGION < (int64_t)a.n_bytes;
-                if (!PAT && a.long_recs != nullptr && (lopen || len <= TKF_LONGCAP)) lres = lopen ? TKF_LONGCAP : len;
+                const bool have_ctl = (lds[TKF_L_CONST + 6] | lds[TKF_L_CONST + 7]) != 0u;
+                if (!PAT && have_ctl && (lopen || len <= TKF_LONGCAP)) lres = lopen ? TKF_LONGCAP : len;
                 else toolong = true;
             } else if (len > 16u && !(DBG && (a.dbg_ablate & 1))) {
                 uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
@@ -793,41 +796,57 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 r = tk_probe_long(t, h1, h2, len, rbytes + pos);
             }
             if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
+            if (wv_ballot(lres != 0u)) {
+                // A batch with a long piece is finished HERE, in the general forms of the bookkeeping below, so that the
+                // common path carries nothing of it (two more spilled scalars there were 1.5 % of the kernel on C2).
+                const bool longp = lres != 0u;
+                const bool lmiss = r == TK_RANK_MAX && !toolong && !longp && !(DBG && (a.dbg_ablate & 2));
+                uint32_t lslot = base_own + idx + E;
+                {
+                    uint32_t tot;
+                    lslot += tkf_scan_excl(lmiss ? len - 1u : longp ? lres - 1u : 0u, lane, &tot);
+                    E += tot;
+                }
+                if (longp) {
+                    // (records, capacity and counter through the control words: see TkFlatArgs::long_ctl)
+                    const uint32_t* ctl = reinterpret_cast<const uint32_t*>(wv_global_ptr((uint64_t)lds[TKF_L_CONST + 6] | ((uint64_t)lds[TKF_L_CONST + 7] << 32)));
+                    TkFlatLongRec* recs = reinterpret_cast<TkFlatLongRec*>(const_cast<uint8_t*>(wv_global_ptr((uint64_t)ctl[0] | ((uint64_t)ctl[1] << 32))));
+                    const uint32_t q = wv_atomic_add(const_cast<uint32_t*>(ctl) - 5, 1u);
+                    if (q < ctl[2]) {
+                        TkFlatLongRec lr;
+                        lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = lslot; lr.len = lopen ? 0u : len; lr.reserved = lres;
+                        recs[q] = lr;
+                    } else {                                // no room for the record: the document is handed back after all
+                        wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
+                    }
+                }
+                if (wv_ballot(lmiss)) {                     // the misses of the batch: queued by class
+                    const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
+                    const uint32_t sh = cls * 8u;
+                    uint32_t ctot;
+                    const uint32_t before = (tkf_scan_excl(lmiss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
+                    if (lmiss) {
+                        const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
+                        mq[qb + before] = TKF_REC(pos, len, lslot);
+                    }
+                    nm0 += ctot & 0xFFu;
+                    nm1 += (ctot >> 8) & 0xFFu;
+                    nm2 += (ctot >> 16) & 0xFFu;
+                    nm3 += ctot >> 24;
+                }
+                wv_lds_sync();                              // positions read before they are overwritten
+                if (act) {
+                    list[idx] = (uint16_t)lslot;
+                    if (!lmiss && !longp && !(DBG && (a.dbg_ablate & 4))) tmp[lslot] = r + t.num_special;
+                }
+                continue;
+            }
         }
         // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
-        const bool longp = lres != 0u;
-        const bool miss = r == TK_RANK_MAX && !toolong && !longp && !(DBG && (a.dbg_ablate & 2));
+        const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
         uint32_t slot = base_own + idx + E;
         const uint64_t MB = wv_ballot(miss);
-        if (wv_ballot(longp)) {                             // rare
-            uint32_t tot;
-            slot += tkf_scan_excl(miss ? len - 1u : longp ? lres - 1u : 0u, lane, &tot);
-            E += tot;
-            if (longp) {
-                const uint32_t q = wv_atomic_add(a.long_count, 1u);
-                if (q < a.long_cap) {
-                    TkFlatLongRec lr;
-                    lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = slot; lr.len = lopen ? 0u : len; lr.reserved = lres;
-                    a.long_recs[q] = lr;
-                } else {                                    // no room for the record: the document is handed back after all
-                    wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
-                }
-            }
-            if (MB) {                                       // the misses of the batch: queued by class (the general form below)
-                const uint32_t cls = (len > 8u ? 1u : 0u) + (len > 16u ? 1u : 0u) + (len > 32u ? 1u : 0u);
-                const uint32_t sh = cls * 8u;
-                uint32_t ctot;
-                const uint32_t before = (tkf_scan_excl(miss ? 1u << sh : 0u, lane, &ctot) >> sh) & 0xFFu;
-                if (miss) {
-                    const uint32_t qb = cls == 0u ? TKF_MISSOFF0 + nm0 : cls == 1u ? TKF_MISSOFF1 + nm1 : cls == 2u ? TKF_MISSOFF2 + nm2 : TKF_MISSOFF3 + nm3;
-                    mq[qb + before] = TKF_REC(pos, len, slot);
-                }
-                nm0 += ctot & 0xFFu;
-                nm1 += (ctot >> 8) & 0xFFu;
-                nm2 += (ctot >> 16) & 0xFFu;
-                nm3 += ctot >> 24;
-            }
-        } else if (MB) {
+        if (MB) {
             // A miss reserves `len` id slots (it cannot produce more ids than bytes): one per piece + (len - 1) more for
             // every miss before it.  The misses are queued in the chunk's own region (no global atomics), records in
             // piece order, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes): the merge kernels run one
@@ -865,7 +884,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
             list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
-            if (!miss && !longp && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
+            if (!miss && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
         }
     }
     if (pass + 1 < npass) {

@@ -136,11 +136,15 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.t = T.host_view();
     // pieces of 65..TKF_LONGCAP bytes stay on the flat path as records (TK_FLAT_LONG=0: they hand their documents back)
     std::vector<TkFlatLongRec> long_recs(n_bytes / 65 + 16);
-    uint32_t long_count = 0;
+    std::vector<uint32_t> ctlblk(24, 0);                    // the context's counter block: counter 11, control words 16..18
+    uint32_t& long_count = ctlblk[11];
     if (!(getenv("TK_FLAT_LONG") && atoi(getenv("TK_FLAT_LONG")) == 0)) {
         fa.long_recs = long_recs.data();
-        fa.long_count = &long_count;
+        fa.long_count = &ctlblk[11];
         fa.long_cap = (uint32_t)long_recs.size();
+        const uint64_t pv = (uint64_t)reinterpret_cast<uintptr_t>(long_recs.data());
+        ctlblk[16] = (uint32_t)pv; ctlblk[17] = (uint32_t)(pv >> 32); ctlblk[18] = fa.long_cap;
+        fa.long_ctl = &ctlblk[16];
     }
     std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
     uint64_t ops = 0;

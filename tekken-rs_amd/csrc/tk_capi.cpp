@@ -130,6 +130,7 @@ struct tk_ctx {
     uint64_t n_long_recs = 0;      // pieces of 65..TKF_LONGCAP bytes the flat path kept (last call)
     void* long_ctl_ptr = nullptr;  // what the control words at counters + 16 describe
     uint32_t long_ctl_cap = 0;
+    bool no_flat_long128 = false;  // TK_FLAT_LONG128=0: every long-piece record takes the single-wave merge
     bool no_flat_long = false;     // TK_FLAT_LONG=0: such pieces hand their documents back (the round-1 behaviour; A / B and tests)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float pipeline_ms = 0.f, encode_ms = 0.f;
@@ -254,6 +255,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         return fail(TK_ERR_RUNTIME);
     }
     if (const char* fl = getenv("TK_FLAT_LONG")) c->no_flat_long = atoi(fl) == 0;
+    if (const char* fl = getenv("TK_FLAT_LONG128")) c->no_flat_long128 = atoi(fl) == 0;
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
     if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
@@ -567,6 +569,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         // longer than TKF_LONGCAP flags its document, so the handed-back documents are counted again afterwards
         if (n_lrec > fa.long_cap) n_lrec = fa.long_cap;
         c->n_long_recs = n_lrec;
+        fa.long_merge128 = c->no_flat_long128 ? 0 : 1;
         const uint32_t lwaves = ((n_lrec < 8192u ? n_lrec : 8192u) + 3u) / 4u * 4u;
         TK_HIP(c, c->scratch.reserve((size_t)lwaves * TKF_LONG_SCRATCH_WORDS * 4));
         TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));

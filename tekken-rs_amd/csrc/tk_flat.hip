@@ -464,17 +464,48 @@ __global__ __launch_bounds__(256) void tk_flat_long_kernel(TkFlatArgs a, uint32_
     const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     uint32_t* my = scratch + wave_id * scratch_words;
     const uint32_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
-    for (;;) {
-        const uint32_t ticket = wv_first(wv_atomic_add_all(work_counter, 1u));   // (all lanes take part: DESIGN.md 4.7)
-        const uint32_t q = ticket / 64u;
-        if (q >= n) break;
-        tk_flat_long_wave(a, pw, q, lane, my);
-    }
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    (void)work_counter;                                      // (records strided over the waves: a ticket per record is an atomic per record)
+    for (uint64_t q = wave_id; q < n; q += n_waves) tk_flat_long_wave(a, pw, (uint32_t)q, lane, my);
+}
+
+// stage two for the records of 65..128 bytes that are no vocabulary keys: one lane per piece (tk_merge_long_wave<128>), two
+// waves per block (32 KB of PAIR filter + 2 x 64 KB of columns), one block per CU.  (The same with 256-entry columns for
+// 129..256 bytes -- 128 KB per wave, ONE wave per CU -- was measured and dropped: 4.4 ms where the single-wave merge of stage
+// one takes 4.7 ms for the same pieces; 64 chains per CU at ~3 us a round are no better than a dozen at 1.1 us a merge.)
+#define TKM_L128_BLOCK 128
+#define TKM_L128_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_L128_BLOCK / 64) * TKM_LDS_WORDS(128)) * 4)
+template <int N, int BLOCK>
+__device__ __forceinline__ void tk_flat_longN_body(const TkFlatArgs& a, uint32_t* wlds) {
+    const uint64_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    if (n == 0) return;                                      // (grid-uniform)
+    tk_merge_load_filter<BLOCK>(a, wlds);
+    const uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
+    uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(N);
+    for (uint64_t w = wave; w * 64 < n; w += n_waves) tk_merge_long_wave<N>(a, w, wv_lane(), mlds, wlds);
+}
+__global__ __launch_bounds__(TKM_L128_BLOCK) void tk_flat_long128_kernel(TkFlatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
+    tk_flat_longN_body<128, TKM_L128_BLOCK>(a, wlds);
 }
 
 hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words, uint32_t n_waves,
                                hipStream_t s) {
     hipLaunchKernelGGL(tk_flat_long_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, s, a, work_counter, scratch, scratch_words);
+    if (a.long_merge128) {
+        static bool attr_set[64] = {false};        // (per device: the LDS opt-in is a per-device function attribute)
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (!attr_set[dev & 63]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tk_flat_long128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    TKM_L128_LDS_BYTES) != hipSuccess)
+                return hipErrorInvalidValue;
+            attr_set[dev & 63] = true;
+        }
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(tk_flat_long128_kernel, dim3((uint32_t)cus), dim3(TKM_L128_BLOCK), TKM_L128_LDS_BYTES, s, a);
+    }
     return hipGetLastError();
 }
 

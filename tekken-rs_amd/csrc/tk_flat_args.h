@@ -61,6 +61,8 @@ struct TkFlatArgs {
     TkFlatLongRec* long_recs;    // [long_cap] pieces of 65..TKF_LONGCAP bytes (what tk_flat_long_kernel reads)
     uint32_t* long_count;        // records appended (may exceed long_cap: the surplus pieces hand their documents back)
     uint32_t long_cap;
+    int long_merge128;           // records of 65..128 bytes that are no vocabulary keys are marked for tk_flat_long128_kernel (one lane per
+                                 // piece); 0: the single-wave merge takes them too
     const uint32_t* long_ctl;    // what the flat kernel reads, in its rare path only, so that the three values above cost it no
                                  // scalar registers: device words {long_recs lo, hi, long_cap}, the record counter five words
                                  // BELOW them (the context's counter block: counter 11, control words at 16..18).  NULL: a piece

@@ -807,12 +807,19 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                     lslot += tkf_scan_excl(lmiss ? len - 1u : longp ? lres - 1u : 0u, lane, &tot);
                     E += tot;
                 }
-                if (longp) {
-                    // (records, capacity and counter through the control words: see TkFlatArgs::long_ctl)
+                {
+                    // (records, capacity and counter through the control words: see TkFlatArgs::long_ctl; ONE atomic for the
+                    // batch's long pieces -- a counter every long piece of the batch bumps on its own serialises in the L2)
+                    const uint64_t LB = wv_ballot(longp);
+                    const int lfirst = tk_ctz64(LB);
                     const uint32_t* ctl = reinterpret_cast<const uint32_t*>(wv_global_ptr((uint64_t)lds[TKF_L_CONST + 6] | ((uint64_t)lds[TKF_L_CONST + 7] << 32)));
+                    uint32_t qbase = 0;
+                    if (lane == lfirst) qbase = wv_atomic_add(const_cast<uint32_t*>(ctl) - 5, (uint32_t)tk_popc64(LB));
+                    qbase = wv_shfl(qbase, lfirst);
+                    const uint32_t q = qbase + (uint32_t)tk_popc64(LB & tk_lowmask(lane));
                     TkFlatLongRec* recs = reinterpret_cast<TkFlatLongRec*>(const_cast<uint8_t*>(wv_global_ptr((uint64_t)ctl[0] | ((uint64_t)ctl[1] << 32))));
-                    const uint32_t q = wv_atomic_add(const_cast<uint32_t*>(ctl) - 5, 1u);
-                    if (q < ctl[2]) {
+                    if (!longp) {
+                    } else if (q < ctl[2]) {
                         TkFlatLongRec lr;
                         lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = lslot; lr.len = lopen ? 0u : len; lr.reserved = lres;
                         recs[q] = lr;
@@ -948,10 +955,17 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     if (r != TK_RANK_MAX) {
         if (lane == 0) out[0] = r + a.t.num_special;
         cur = 1;
+    } else if (len <= 128u && a.long_merge128) {
+        // up to 128 bytes: merged one lane per piece by tk_flat_long128_kernel (64 chains per wave instead of one); the
+        // record keeps its length and a mark (no list, no counter: that kernel walks all records)
+        if (lane == 0) {
+            a.long_recs[q].len = len;
+            a.long_recs[q].reserved = lr.reserved | 0x80000000u;
+        }
+        return;
     } else {
         tk_piece_merge_coop(ea, lane, g, e, out, cur, scratch);
     }
-    (void)len;
     for (uint32_t k = cur + (uint32_t)lane; k < lr.reserved; k += 64u) out[k] = TKF_HOLE;
     if (lane == 0) wv_atomic_add(a.holes + d, lr.reserved - cur);
 }
@@ -1090,20 +1104,30 @@ TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane,
 #endif
 template <int N> struct TkmAlive { typedef uint32_t type; };
 template <> struct TkmAlive<64> { typedef uint64_t type; };
+template <> struct TkmAlive<128> { typedef unsigned __int128 type; };
+// mask helpers: the low n bits (n up to the width), one bit, any bit set, lowest set bit cleared (the type is chosen by
+// a null pointer argument)
+template <typename T> TK_DEV T tkm_low(uint32_t n, const T*) { return n >= 8u * (uint32_t)sizeof(T) ? (T)~(T)0 : (T)(((T)1 << n) - (T)1); }
+template <typename T> TK_DEV T tkm_bit(uint32_t n, const T*) { return (T)((T)1 << n); }
+template <typename T> TK_DEV bool tkm_any(T v) { return v != (T)0; }
+template <typename T> TK_DEV T tkm_clear_lowest(T v) { return (T)(v & (v - (T)1)); }
 TK_DEV uint32_t tkm_ctz(uint32_t v) { return (uint32_t)__builtin_ctz(v); }
 TK_DEV uint32_t tkm_ctz(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 TK_DEV uint32_t tkm_msb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 TK_DEV uint32_t tkm_msb(uint64_t v) { return 63u - (uint32_t)__builtin_clzll(v); }
 TK_DEV uint32_t tkm_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
 TK_DEV uint32_t tkm_popc(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+TK_DEV uint32_t tkm_ctz(unsigned __int128 v) { const uint64_t lo = (uint64_t)v; return lo ? (uint32_t)__builtin_ctzll(lo) : 64u + (uint32_t)__builtin_ctzll((uint64_t)(v >> 64)); }
+TK_DEV uint32_t tkm_msb(unsigned __int128 v) { const uint64_t hi = (uint64_t)(v >> 64); return hi ? 127u - (uint32_t)__builtin_clzll(hi) : 63u - (uint32_t)__builtin_clzll((uint64_t)v); }
+TK_DEV uint32_t tkm_popc(unsigned __int128 v) { return (uint32_t)__builtin_popcountll((uint64_t)v) + (uint32_t)__builtin_popcountll((uint64_t)(v >> 64)); }
 
-// N = 8, 16, 32, 64 (64: the class 33..64 bytes; keys carry six position bits and the live mask is 64 bits wide)
+// N = 8, 16, 32, 64, 128 (64: the class 33..64 bytes, keys carry six position bits and the live mask is 64 bits wide;
+// 128: the long-piece records of 65..128 bytes, seven position bits, a 128-bit mask)
 template <int N>
 TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool mine, const uint32_t* kk, uint32_t len,
                              uint32_t* out, uint32_t* mlds, int lane) {
     typedef typename TkmAlive<N>::type alive_t;
-    constexpr uint32_t PB = N > 32 ? 6u : 5u, PM = (1u << PB) - 1u;
-    constexpr alive_t ONE = 1;
+    constexpr uint32_t PB = N > 64 ? 7u : N > 32 ? 6u : 5u, PM = (1u << PB) - 1u;
     const TkTablesView& t = a.t;
     uint32_t* tokc = mlds + lane;
     uint32_t* keyc = mlds + N * 64 + lane;
@@ -1120,7 +1144,7 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
         tokc[i * 64] = b;
         keyc[i * 64] = key;
     }
-    alive_t alive = n >= 8u * (uint32_t)sizeof(alive_t) ? (alive_t)~(alive_t)0 : (alive_t)((ONE << n) - ONE);
+    alive_t alive = tkm_low(n, (const alive_t*)nullptr);
     bool active = mine && !TKM_AB(a, 1024);
     while (wv_ballot(active)) {
         if (active) {
@@ -1135,15 +1159,15 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
             } else {
                 // the parts at bi and at the next live position j become one part (at bi) whose id is the rank
                 const uint32_t bi = best & PM, rank = best >> PB;
-                const alive_t above = alive & ~(((alive_t)2 << bi) - ONE);   // bi <= N - 2
+                const alive_t above = alive & ~tkm_low(bi + 1u, (const alive_t*)nullptr);       // bi <= N - 2
                 const uint32_t j = tkm_ctz(above);                            // exists: key[bi] was a pair
-                const alive_t above2 = above & (above - ONE);
-                const alive_t below = alive & ((ONE << bi) - ONE);
-                const bool has_next = above2 != 0, has_prev = below != 0;
+                const alive_t above2 = tkm_clear_lowest(above);
+                const alive_t below = alive & tkm_low(bi, (const alive_t*)nullptr);
+                const bool has_next = tkm_any(above2), has_prev = tkm_any(below);
                 const uint32_t k = has_next ? tkm_ctz(above2) : 0u;
                 const uint32_t p = has_prev ? tkm_msb(below) : 0u;
                 const uint32_t tn = tokc[k * 64], tp = tokc[p * 64];
-                alive &= ~(ONE << j);
+                alive = alive & ~tkm_bit(j, (const alive_t*)nullptr);
                 tokc[bi * 64] = rank;
                 keyc[j * 64] = 0xFFFFFFFFu;
                 uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
@@ -1163,10 +1187,10 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
             uint32_t v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t pos = rem ? tkm_ctz(rem) : 0u;
+                const uint32_t pos = tkm_any(rem) ? tkm_ctz(rem) : 0u;
                 const uint32_t id = tokc[pos * 64] + t.num_special;
                 v[q] = (uint32_t)(q0 + q) < np ? id : TKF_HOLE;
-                rem &= rem - ONE;
+                rem = tkm_clear_lowest(rem);
             }
             if ((uint32_t)q0 + 4u <= len) {
                 wv_store16(out + q0, v[0], v[1], v[2], v[3]);
@@ -1224,6 +1248,42 @@ TK_DEV void tk_merge_items64(const TkFlatArgs& a, bool have, uint32_t rec, uint3
     uint32_t holes = 0;
     if (wv_ballot(have)) holes = tk_merge_lds<64>(a, filt, have, kk, len, out, mlds, lane);
     tk_merge_holes(a, have, holes, chunk, g, lane);
+}
+
+// the long-piece records that are no vocabulary keys (marked by tk_flat_long_wave): 64 consecutive records per wave, one
+// lane each, in N-entry LDS columns -- N = 128 for 65..128 bytes (64 KB per wave: two waves and the PAIR filter fill a CU's
+// LDS) -- still 128 chains per CU where the single-wave merge runs a dozen
+template <int N>
+TK_DEV void tk_merge_long_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, uint32_t* mlds, const uint32_t* filt) {
+    const uint64_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    const uint64_t item = wave_id * 64 + (uint64_t)lane;
+    if (wave_id * 64 >= n) return;                    // wave-uniform
+    TkFlatLongRec lr;
+    lr.pos = 0; lr.chunk = 0; lr.slot = 0; lr.len = 0; lr.reserved = 0;
+    if (item < n) lr = a.long_recs[item];
+    // marked by tk_flat_long_wave, and of this kernel's length class
+    const bool have = (lr.reserved & 0x80000000u) != 0u && lr.len <= (uint32_t)N && lr.len > (uint32_t)N / 2u;
+    lr.reserved &= 0x7FFFFFFFu;
+    if (wv_ballot(have) == 0ull) return;
+    const int64_t g = (int64_t)lr.pos;
+    uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;
+    uint32_t kk[N / 4];
+    for (int q = 0; q < N / 4; ++q) kk[q] = 0u;
+    if (have) {
+        if (g + N <= (int64_t)a.n_bytes) {
+#pragma unroll
+            for (int q = 0; q < N / 16; ++q) wv_load16(a.bytes + g + 16 * q, kk + 4 * q);
+        } else {
+            for (uint32_t q = 0; q < lr.len; ++q) kk[q >> 2] |= (uint32_t)a.bytes[g + q] << (8 * (q & 3));
+        }
+    }
+    uint32_t holes = tk_merge_lds<N>(a, filt, have, kk, lr.len, out, mlds, lane);
+    if (have) {
+        // (a piece whose end the chunk did not see reserved TKF_LONGCAP slots: the rest are holes too)
+        for (uint32_t k = lr.len; k < lr.reserved; ++k) out[k] = TKF_HOLE;
+        holes += lr.reserved - lr.len;
+    }
+    tk_merge_holes(a, have, holes, lr.chunk, g, lane);
 }
 
 template <bool WIDE>

@@ -202,10 +202,12 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             ops += tkemu::g_wave->n_ops;
         }
     }
-    // the long-piece records (tk_flat_long_kernel): one wave each; a piece beyond TKF_LONGCAP flags its document
+    // the long-piece records (tk_flat_long_kernel): one wave each; a piece beyond TKF_LONGCAP flags its document; those of up
+    // to 128 bytes that are no vocabulary keys go on to the lane-per-piece merge (tk_flat_long128_kernel)
     {
         std::vector<uint32_t> lscratch(TKF_LONG_SCRATCH_WORDS + 64, 0xDEADBEEFu);
         const uint32_t nl = long_count < fa.long_cap ? long_count : fa.long_cap;
+        fa.long_merge128 = (getenv("TK_FLAT_LONG128") && atoi(getenv("TK_FLAT_LONG128")) == 0) ? 0 : 1;
         for (uint32_t q = 0; q < nl; ++q) {
             tkemu::run_wave([&](int lane) {
                 const TkPolyPow pw = tk_poly_pow(fa.t, lane);
@@ -214,6 +216,15 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             ops += tkemu::g_wave->n_ops;
             for (size_t i = 0; i < 64; ++i)
                 if (lscratch[TKF_LONG_SCRATCH_WORDS + i] != 0xDEADBEEFu) { g_err = "tk_flat_long_wave wrote past its scratch"; return TK_ERR_RUNTIME; }
+        }
+        const size_t G2 = 256;
+        std::vector<uint32_t> mldsN(G2 + TKM_LDS_WORDS(128) + G2, 0xDEADBEEFu);
+        for (uint64_t w = 0; fa.long_merge128 && w * 64 < nl; ++w) {
+            std::fill(mldsN.begin(), mldsN.end(), 0xDEADBEEFu);
+            tkemu::run_wave([&](int lane) { tk_merge_long_wave<128>(fa, w, lane, mldsN.data() + G2, fa.t.pair_filter); });
+            ops += tkemu::g_wave->n_ops;
+            for (size_t i = 0; i < G2; ++i)
+                if (mldsN[i] != 0xDEADBEEFu || mldsN[G2 + TKM_LDS_WORDS(128) + i] != 0xDEADBEEFu) { g_err = "tk_merge_long_wave wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
         }
     }
     // flagged documents -> per-document algorithm

@@ -93,6 +93,10 @@ uint64_t tk_small_path_calls(const tk_ctx* ctx);
 /* Documents so far whose long piece (>= 1 KiB, not a vocabulary key) was merged in rounds by a whole workgroup
  * (csrc/tk_long.hip) instead of step by step by one wave (diagnostics / tests; TK_LONG_MIN overrides the threshold). */
 uint64_t tk_round_path_docs(const tk_ctx* ctx);
+/* Pieces of 65..256 bytes of the LAST batch that stayed on the flat path as records (csrc/tk_flat_impl.h step 6) instead of
+ * handing their documents to the per-document kernels (diagnostics / tests; TK_FLAT_LONG=0 at context creation switches
+ * the path off, TK_FLAT_LONG128=0 its one-lane-per-piece merge). */
+uint64_t tk_long_piece_records(const tk_ctx* ctx);
 
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference

@@ -110,6 +110,8 @@ def lib():
     L.tk_small_path_calls.argtypes = [vp]
     L.tk_round_path_docs.restype = ctypes.c_uint64
     L.tk_round_path_docs.argtypes = [vp]
+    L.tk_long_piece_records.restype = ctypes.c_uint64
+    L.tk_long_piece_records.argtypes = [vp]
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
@@ -324,6 +326,10 @@ class Engine:
     def round_path_docs(self):
         """Documents so far whose long piece was merged in rounds by a workgroup (csrc/tk_long.hip)."""
         return int(lib().tk_round_path_docs(self._h))
+
+    def long_piece_records(self):
+        """Pieces of 65..256 bytes of the last batch that stayed on the flat path as records."""
+        return int(lib().tk_long_piece_records(self._h))
 
     def small_path_calls(self):
         """Calls served by the one-launch small-batch path so far."""

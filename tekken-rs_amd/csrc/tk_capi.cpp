@@ -1092,6 +1092,7 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
 
 extern "C" uint64_t tk_small_path_calls(const tk_ctx* c) { return c ? c->n_small_calls : 0; }
 extern "C" uint64_t tk_round_path_docs(const tk_ctx* c) { return c ? c->n_round_docs : 0; }
+extern "C" uint64_t tk_long_piece_records(const tk_ctx* c) { return c ? c->n_long_recs : 0; }
 
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;

@@ -23,8 +23,9 @@
 // ends), the rest committed (1952 bytes of 2048).  ASCII is classified from the bit planes alone; a region with multi-byte code
 // points additionally looks the class of every lead byte up in the trie (the char-level rules use the
 // char-start mask).  A document with a digit / CR-LF run that covers the whole left halo, a white-space
-// run that reaches the end of the region or a piece of more than 64 bytes is flagged and redone by the
-// per-document kernel (tk_encode_impl.h), which handles everything.
+// run that reaches the end of the region or a piece of more than TKF_LONGCAP (256) bytes is flagged and redone by the
+// per-document kernel (tk_encode_impl.h), which handles everything.  A piece of 65..256 bytes becomes a RECORD
+// (step 6: slots reserved, the merge left to tk_flat_long_wave / tk_merge_long_wave) and its document stays here.
 //
 // The rules are modelled in tools/flat_split_model.py (Python ints as masks, checked against the
 // oracle); this file is that model in lane layout.  Runs on the CPU wave emulator (tests/emu).

@@ -653,11 +653,12 @@ def test_long_pieces_stay_on_the_flat_path(tk, eng_small, eng_bench, test_vocab,
         orc = helpers.oracle_for(v)
         ids, oo = check_batch(eng, orc, data, offs)
         assert eng.last_stats()["handed_back"] == len(handed)
+        assert eng.long_piece_records() > 2000          # (the CJK paragraphs alone hold a few thousand such pieces)
         check_batch(eng, orc, data, offs, False, False)
     monkeypatch.setenv("TK_FLAT_LONG", "0")
     e0 = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
     ids0, oo0 = e0.encode_batch(data, offs, True, True)
-    assert e0.last_stats()["handed_back"] > len(handed)
+    assert e0.last_stats()["handed_back"] > len(handed) and e0.long_piece_records() == 0
     assert np.array_equal(ids0, ids) and np.array_equal(oo0, oo)
     e0.close()
 

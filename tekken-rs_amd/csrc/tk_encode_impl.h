@@ -740,6 +740,89 @@ TK_DEV void tk_piece_merge_coop(const TkEncodeArgs& a, int lane, uint64_t w0, ui
 }
 
 // ------------------------------------------------------------------------------------------
+// The byte-pair merge of ONE piece of up to 256 bytes by one wave with the parts in REGISTERS: position p = 64 j + lane
+// (j = 0..3) holds the id of the part that starts there and the rank of its pair with the next part; four wave-uniform
+// 64-bit masks say which positions are live.  A merge (tiktoken's order: the leftmost smallest rank) is one wave
+// minimum, a few bit scans over the masks for the neighbours, two readlanes for their ids, ONE round trip for the two
+// pairs the merge creates, and a handful of predicated moves -- no memory but the probes.  (tk_piece_merge_coop keeps
+// the parts of a piece of ANY length in scratch and refreshes block minima from 64-lane rows: three wave-wide gathers
+// per merge, which is what bounded it on pieces this short -- ~3 merges per microsecond and CU whatever the occupancy.)
+// ------------------------------------------------------------------------------------------
+TK_DEV uint32_t tkp_sel4(const uint32_t* v, uint32_t j) { return j == 0u ? v[0] : j == 1u ? v[1] : j == 2u ? v[2] : v[3]; }
+TK_DEV uint64_t tkp_sel4(const uint64_t* v, uint32_t j) { return j == 0u ? v[0] : j == 1u ? v[1] : j == 2u ? v[2] : v[3]; }
+// first live position above pos (256: none) / last live position below pos (TK_NONE: none); A, pos wave-uniform
+TK_DEV uint32_t tkp_next(const uint64_t* A, uint32_t pos) {
+    const uint32_t j = pos >> 6, l = pos & 63u;
+    const uint64_t m = l < 63u ? (tkp_sel4(A, j) >> (l + 1u)) << (l + 1u) : 0ull;
+    if (m) return 64u * j + (uint32_t)__builtin_ctzll(m);
+    for (uint32_t jj = j + 1u; jj < 4u; ++jj) {
+        const uint64_t a = tkp_sel4(A, jj);
+        if (a) return 64u * jj + (uint32_t)__builtin_ctzll(a);
+    }
+    return 256u;
+}
+TK_DEV uint32_t tkp_prev(const uint64_t* A, uint32_t pos) {
+    const uint32_t j = pos >> 6, l = pos & 63u;
+    const uint64_t m = tkp_sel4(A, j) & ((1ull << l) - 1ull);
+    if (m) return 64u * j + 63u - (uint32_t)__builtin_clzll(m);
+    for (uint32_t jj = j; jj-- > 0u;) {
+        const uint64_t a = tkp_sel4(A, jj);
+        if (a) return 64u * jj + 63u - (uint32_t)__builtin_clzll(a);
+    }
+    return TK_NONE;
+}
+TK_DEV void tk_piece_merge_small(const TkTablesView& t, const uint8_t* bytes, int lane, uint64_t w0, uint32_t n, uint32_t* out,
+                                 uint32_t& cursor) {
+    uint32_t tok[4], rk[4];
+    uint64_t A[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t p = 64u * j + (uint32_t)lane;
+        const uint32_t b0 = p < n ? (uint32_t)bytes[w0 + p] : 0u;
+        const uint32_t b1 = p + 1u < n ? (uint32_t)bytes[w0 + p + 1u] : 0u;
+        tok[j] = b0;
+        rk[j] = p + 1u < n ? t.pair2[b0 | (b1 << 8)] : TK_RANK_MAX;
+        A[j] = wv_first64(n >= 64u * (j + 1u) ? ~0ull : n <= 64u * j ? 0ull : ((1ull << (n - 64u * j)) - 1ull));
+    }
+    for (uint32_t merges = 0; merges < n; ++merges) {          // at most n - 1 merges can happen
+        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t k = rk[j] == TK_RANK_MAX ? 0xFFFFFFFFu : ((rk[j] << 8) | (64u * j + (uint32_t)lane));
+            key = k < key ? k : key;
+        }
+        key = wv_first(wv_min_u32(key));
+        if (key == 0xFFFFFFFFu) break;                         // wave-uniform
+        const uint32_t i = key & 255u, rr = key >> 8;
+        // (readfirstlane on everything that is the same in all lanes: the mask arithmetic then runs on the scalar unit)
+        const uint32_t jn = wv_first(tkp_next(A, i));           // exists: the pair at i was live
+        const uint32_t nn = wv_first(tkp_next(A, jn)), p = wv_first(tkp_prev(A, i));
+        const uint32_t tok_nn = nn < 256u ? wv_shfl(tkp_sel4(tok, nn >> 6), (int)(nn & 63u)) : 0u;
+        const uint32_t tok_p = p != TK_NONE ? wv_shfl(tkp_sel4(tok, p >> 6), (int)(p & 63u)) : 0u;
+        uint32_t new_i, new_p;
+        tk_probe_pair_x2(t, rr, tok_nn, tok_p, rr, new_i, new_p);   // (every lane asks for the same two buckets: one request each)
+        if (nn >= 256u) new_i = TK_RANK_MAX;
+        if (p == TK_NONE) new_p = TK_RANK_MAX;
+        // the part at i takes the merged id and its new pair rank, the part at jn dies, the part at p gets its new pair rank
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t pos = 64u * j + (uint32_t)lane;
+            if (pos == i) { tok[j] = rr; rk[j] = new_i; }
+            if (pos == jn) rk[j] = TK_RANK_MAX;
+            if (p != TK_NONE && pos == p) rk[j] = new_p;
+            if ((jn >> 6) == j) A[j] = wv_first64(A[j] & ~(1ull << (jn & 63u)));
+        }
+    }
+    uint32_t base = cursor;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        if ((A[j] >> lane) & 1ull) out[base + (uint32_t)tk_popc64(A[j] & tk_lowmask(lane))] = tok[j] + t.num_special;
+        base += (uint32_t)tk_popc64(A[j]);
+    }
+    cursor = base;
+}
+
+// ------------------------------------------------------------------------------------------
 // one document
 // ------------------------------------------------------------------------------------------
 // MODE 0: pass 1 (a document whose first unfinished piece does not end inside a window is handed

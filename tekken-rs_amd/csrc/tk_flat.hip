@@ -492,6 +492,16 @@ __global__ __launch_bounds__(TKM_L128_BLOCK) void tk_flat_long128_kernel(TkFlatA
     tk_flat_longN_body<128, TKM_L128_BLOCK>(a, wlds);
 }
 
+// stage two for the marked records of 129..TKF_LONGCAP bytes: the single-wave merge alone, records strided over the waves
+__global__ __launch_bounds__(256) void tk_flat_long_coop_kernel(TkFlatArgs a, uint32_t* scratch, uint32_t scratch_words) {
+    const int lane = wv_lane();
+    const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t* my = scratch + wave_id * scratch_words;
+    const uint32_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t q = wave_id; q < n; q += n_waves) tk_flat_long_coop_wave(a, (uint32_t)q, lane, my);
+}
+
 hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words, uint32_t n_waves,
                                hipStream_t s) {
     hipLaunchKernelGGL(tk_flat_long_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, s, a, work_counter, scratch, scratch_words);
@@ -507,6 +517,7 @@ hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint
         }
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         hipLaunchKernelGGL(tk_flat_long128_kernel, dim3((uint32_t)cus), dim3(TKM_L128_BLOCK), TKM_L128_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(tk_flat_long_coop_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, s, a, scratch, scratch_words);
     }
     return hipGetLastError();
 }

@@ -956,17 +956,37 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     if (r != TK_RANK_MAX) {
         if (lane == 0) out[0] = r + a.t.num_special;
         cur = 1;
-    } else if (len <= 128u && a.long_merge128) {
-        // up to 128 bytes: merged one lane per piece by tk_flat_long128_kernel (64 chains per wave instead of one); the
-        // record keeps its length and a mark (no list, no counter: that kernel walks all records)
+    } else if (a.long_merge128) {
+        // not a vocabulary key: the merge is left to the kernels that do nothing else -- up to 128 bytes one lane per piece
+        // (tk_flat_long128_kernel: 64 chains per wave instead of one), beyond that the single-wave merge in a kernel of
+        // its own (tk_flat_long_coop_kernel: this one's matcher and lookup cost it half its waves).  The record keeps
+        // its length and a mark (no list, no counter: those kernels walk all records).
         if (lane == 0) {
             a.long_recs[q].len = len;
-            a.long_recs[q].reserved = lr.reserved | 0x80000000u;
+            a.long_recs[q].reserved = lr.reserved | (len <= 128u ? 0x80000000u : 0x40000000u);
         }
         return;
     } else {
         tk_piece_merge_coop(ea, lane, g, e, out, cur, scratch);
     }
+    for (uint32_t k = cur + (uint32_t)lane; k < lr.reserved; k += 64u) out[k] = TKF_HOLE;
+    if (lane == 0) wv_atomic_add(a.holes + d, lr.reserved - cur);
+}
+
+// a record of 129..TKF_LONGCAP bytes that tk_flat_long_wave marked: one wave merges it with the parts in registers
+TK_DEV void tk_flat_long_coop_wave(const TkFlatArgs& a, uint32_t q, int lane, uint32_t* scratch) {
+    TkFlatLongRec lr = a.long_recs[q];
+    if (wv_first(lr.reserved & 0x40000000u) == 0u) return;
+    lr.reserved &= 0x3FFFFFFFu;
+    const uint64_t g = lr.pos;
+    uint64_t d = a.first_doc[lr.chunk];
+    d = d > 0 ? d - 1 : 0;
+    while (d + 1 < a.n_docs && a.doc_offs[d + 1] <= g) ++d;
+    d = wv_first64(d);
+    uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;
+    uint32_t cur = 0;
+    (void)scratch;
+    tk_piece_merge_small(a.t, a.bytes, lane, g, lr.len, out, cur);   // (<= TKF_LONGCAP = 256 bytes: the parts in registers)
     for (uint32_t k = cur + (uint32_t)lane; k < lr.reserved; k += 64u) out[k] = TKF_HOLE;
     if (lane == 0) wv_atomic_add(a.holes + d, lr.reserved - cur);
 }
@@ -1264,7 +1284,7 @@ TK_DEV void tk_merge_long_wave(const TkFlatArgs& a, uint64_t wave_id, int lane, 
     if (item < n) lr = a.long_recs[item];
     // marked by tk_flat_long_wave, and of this kernel's length class
     const bool have = (lr.reserved & 0x80000000u) != 0u && lr.len <= (uint32_t)N && lr.len > (uint32_t)N / 2u;
-    lr.reserved &= 0x7FFFFFFFu;
+    lr.reserved &= 0x3FFFFFFFu;
     if (wv_ballot(have) == 0ull) return;
     const int64_t g = (int64_t)lr.pos;
     uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;

@@ -226,6 +226,12 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             for (size_t i = 0; i < G2; ++i)
                 if (mldsN[i] != 0xDEADBEEFu || mldsN[G2 + TKM_LDS_WORDS(128) + i] != 0xDEADBEEFu) { g_err = "tk_merge_long_wave wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
         }
+        for (uint32_t q = 0; fa.long_merge128 && q < nl; ++q) {
+            tkemu::run_wave([&](int lane) { tk_flat_long_coop_wave(fa, q, lane, lscratch.data()); });
+            ops += tkemu::g_wave->n_ops;
+            for (size_t i = 0; i < 64; ++i)
+                if (lscratch[TKF_LONG_SCRATCH_WORDS + i] != 0xDEADBEEFu) { g_err = "tk_flat_long_coop_wave wrote past its scratch"; return TK_ERR_RUNTIME; }
+        }
     }
     // flagged documents -> per-document algorithm
     std::vector<uint32_t> todo;

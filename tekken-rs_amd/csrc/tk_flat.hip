@@ -8,7 +8,8 @@
 //   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
 //   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32- and 64-entry LDS columns)
 //   tk_flat_long_kernel       the records of pieces of 65..256 bytes: end of the piece where the chunk did not see it, whole-piece
-//                             lookup, single-wave merge (129..256 bytes); tk_flat_long128_kernel: 65..128 bytes, one lane per piece
+//                             lookup; tk_flat_long128_kernel: 65..128 bytes, one lane per piece; tk_flat_long_coop_kernel:
+//                             129..256 bytes, one wave per piece with the parts in registers
 //   tk_flat_todo_kernel       flagged documents -> list for the per-document kernel
 //   tk_flat_counts_kernel     ids per document from the chunk prefix sums and the document-start ranks
 //   tk_flat_assemble_kernel   chunk-dense ids -> packed ids in document order with BOS / EOS

@@ -120,6 +120,7 @@ struct tk_ctx {
     DevBuf f_long;             // flat path: records of the pieces of 65..TKF_LONGCAP bytes
     DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
     DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
+    uint32_t long_lazy_mul = 0;    // TK_LONG_LAZY_MUL (0 = the default of tk_piece_is_long)
     uint32_t long_min = 1024;      // shortest piece (bytes) merged in rounds by a workgroup (TK_LONG_MIN; 0 = never)
     uint32_t long_force = 0;       // TK_LONG_FORCE (tests): rounds for every long piece, not only the repetitive ones
     uint64_t n_round_docs = 0;     // documents the round-based kernel took in the last call
@@ -257,6 +258,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     if (const char* fl = getenv("TK_FLAT_LONG")) c->no_flat_long = atoi(fl) == 0;
     if (const char* fl = getenv("TK_FLAT_LONG128")) c->no_flat_long128 = atoi(fl) == 0;
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
+    if (const char* lz = getenv("TK_LONG_LAZY_MUL")) c->long_lazy_mul = (uint32_t)atoi(lz);
     if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
         c->pipeline_forced = strcmp(pl, "doc") == 0 ? 2 : strcmp(pl, "flat") == 0 ? 1 : 0;
@@ -337,6 +339,7 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
         a.long_list = (uint32_t*)c->long_list.p;
         a.long_count = d_long_count;
         a.long_min = c->long_min < 65u ? 65u : c->long_min;
+        a.long_lazy_mul = c->long_lazy_mul;
         a.long_force = c->long_force;
     }
     TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));

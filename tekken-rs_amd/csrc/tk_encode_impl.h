@@ -492,14 +492,16 @@ TK_DEV uint64_t tk_match_end2(const TkTablesView& t, const uint8_t* b, uint64_t 
 // thresholds, so every kernel that asks gets the same answer): 0 = one merge per step by this wave; 1 = the compacting
 // rounds of tk_long.hip (repetitive pieces of >= long_min bytes: thousands of occurrences per rank -- 15x); 2 = the lazy
 // rounds (pieces with many distinct pairs of >= 4 long_min bytes: 2.3x at 32 KiB, break-even near 4 KiB; below that the
-// rounds' fixed cost of ~5 us loses against a dozen steps of 1.1 us).  long_force (tests): 1 / 2 = every long piece there.
+// rounds' fixed cost of ~5 us loses against a dozen steps of 1.1 us -- but a job of the rounds has a CU of its own while the
+// single-wave merge holds up the kernel that walks ALL handed-back documents, so the threshold is 2 long_min: Zipf shape,
+// 500 k documents 10.0 -> 9.15 ms, 4 M documents 32.2 -> 32.6 ms).  long_force (tests): 1 / 2 = every long piece there.
 TK_DEV bool tk_piece_repetitive(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e);
 TK_DEV uint32_t tk_piece_is_long(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e) {
     const uint64_t len = e - w0;
     if (len < (uint64_t)a.long_min || len > TK_LONG_MAX) return 0u;
     if (a.long_force) return a.long_force == 1u ? 1u : 2u;
     if (tk_piece_repetitive(a, lane, w0, e)) return 1u;
-    return len >= 4ull * a.long_min ? 2u : 0u;
+    return len >= (uint64_t)(a.long_lazy_mul ? a.long_lazy_mul : 2u) * a.long_min ? 2u : 0u;
 }
 
 // whole-piece lookup of the piece [w0, e): its rank or TK_RANK_MAX (wave-uniform)

@@ -24,6 +24,7 @@ struct TkEncodeArgs {
     uint32_t* long_list;        // pass 2: documents with a long piece that misses the vocabulary, handed on to tk_long.hip (NULL: merged here)
     uint32_t* long_count;
     uint32_t long_min;          // shortest piece (bytes) that counts as long
+    uint32_t long_lazy_mul;     // a piece with many distinct pairs takes the lazy rounds from long_lazy_mul * long_min bytes on (0 = 2)
     uint32_t long_force;        // tests: every long piece takes the round-based merge, repetitive or not
     TkLongJob* long_jobs;       // tk_long.hip: the long pieces of the documents of the long list
     uint32_t* long_job_count;

@@ -941,7 +941,7 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     ea.bytes = a.bytes; ea.doc_offs = a.doc_offs; ea.n_docs = a.n_docs; ea.staging = nullptr; ea.counts = nullptr;
     ea.work_counter = nullptr; ea.defer_count = nullptr; ea.defer_list = nullptr; ea.todo_list = nullptr; ea.n_todo = 0;
     ea.scratch = scratch; ea.scratch_words_per_wave = 0; ea.add_bos = 0; ea.add_eos = 0; ea.split_only = 0; ea.pattern = 0; ea.dbg_ablate = 0;
-    ea.dbg_starts = nullptr; ea.dbg_mark = nullptr; ea.long_list = nullptr; ea.long_count = nullptr; ea.long_min = 0; ea.long_force = 0;
+    ea.dbg_starts = nullptr; ea.dbg_mark = nullptr; ea.long_list = nullptr; ea.long_count = nullptr; ea.long_min = 0; ea.long_lazy_mul = 0; ea.long_force = 0;
     ea.long_jobs = nullptr; ea.long_job_count = nullptr; ea.long_job_cap = 0; ea.t = a.t;
     const uint64_t s1 = wv_first64(a.doc_offs[d + 1]);
     const uint64_t e = lr.len ? g + lr.len : wv_first64(tk_match_end(a.t, a.bytes, g, s1));

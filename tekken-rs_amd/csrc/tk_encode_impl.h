@@ -572,10 +572,16 @@ TK_DEV void tk_piece_coop(const TkEncodeArgs& a, const TkPolyPow& pw, int lane, 
 // the wave-cooperative merge of a piece that is not a vocabulary key (one merge per step, tiktoken's order)
 // light (a compile-time constant at every call site): only the plain form with the block minima in scratch -- fewer registers,
 // for the workgroup-per-document kernel, whose 1024-thread blocks leave a wave 128 of them
+TK_DEV void tk_piece_merge_small(const TkTablesView& t, const uint8_t* bytes, int lane, uint64_t w0, uint32_t n, uint32_t* out,
+                                 uint32_t& cursor);
 TK_DEV void tk_piece_merge_coop(const TkEncodeArgs& a, int lane, uint64_t w0, uint64_t e, uint32_t* out, uint32_t& cursor, uint32_t* scratch,
                                 bool light) {
     const TkTablesView& t = a.t;
     const uint64_t n = e - w0;
+    if (n <= 256u && !a.dbg_mark) {            // short enough for the parts to live in registers: no scratch traffic at all
+        tk_piece_merge_small(t, a.bytes, lane, w0, (uint32_t)n, out, cursor);
+        return;
+    }
 
     // ---- wave-cooperative merge over scratch: node[nn] = {tok, prk, nxt, prv} (16 B) | bmin[nb] (u64) ----
     // prk = rank of the pair (this part, next part); bmin[b] = min over the 64 nodes of block b of

@@ -305,6 +305,46 @@ def test_full_size_mixed_utf8_properties(tk, eng_bench, bench_vocab):
         assert tk_oracle.fnv1a(got) == tk_oracle.fnv1a(eids) and len(got) == len(eids)
 
 
+def test_zipf_shape_properties(tk, eng_bench, bench_vocab):
+    """The shape of BASELINE configs[4] at one GPU's share (500 k documents of 16 B .. 32 KiB, 1.14 GB, resident in HBM): every
+    route at once -- flat path, long-piece records, handed-back documents, the round-based workgroup merges.  Determinism,
+    the GPU batch decode gives the text back byte for byte, one BOS / EOS per document, and three samples of 20 000
+    documents id for id against the oracle."""
+    import torch
+    n_docs = 500_000
+    data, offs = corpus.generate("zipf", n_docs, 0, seed=corpus.BASE_SEED + 1)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    sums = []
+    for _ in range(2):
+        v_ids, v_oo = eng_bench.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, len(data), True, True, stream)
+        ids = torch.as_tensor(v_ids, device="cuda")
+        oo = torch.as_tensor(v_oo, device="cuda")
+        ids_h = ids.cpu().numpy().view(np.uint32)
+        oo_h = oo.cpu().numpy().astype(np.uint64)
+        sums.append(tk_oracle.fnv1a(ids_h))
+    assert sums[0] == sums[1]
+    st = eng_bench.last_stats()
+    assert 0 < st["handed_back"] < 2000 and eng_bench.long_piece_records() > 0 and eng_bench.round_path_docs() > 0
+    ids_keep, oo_keep = ids.clone(), oo.clone()
+    v_b, _ = eng_bench.decode_batch_device(ids_keep.data_ptr(), oo_keep.data_ptr(), n_docs, ids_keep.numel(), tk.SpecialTokenPolicy.Ignore, stream)
+    back = torch.as_tensor(v_b, device="cuda")
+    assert back.numel() == len(data) and bool(torch.equal(back, d_bytes))
+    del back, ids_keep, oo_keep
+    assert int(oo_h[-1]) == len(ids_h) and np.all(np.diff(oo_h.astype(np.int64)) >= 2)
+    first = oo_h[:-1].astype(np.int64)
+    last = oo_h[1:].astype(np.int64) - 1
+    assert np.all(ids_h[first] == bench_vocab["bos"]) and np.all(ids_h[last] == bench_vocab["eos"])
+    orc = helpers.oracle_for(bench_vocab)
+    for lo in (0, 240_000, 480_000):
+        hi = lo + 20_000
+        sub_offs = offs[lo:hi + 1] - offs[lo]
+        eids, _ = orc.encode_batch(data[int(offs[lo]):int(offs[hi])], sub_offs, True, True, threads=16)
+        got = ids_h[int(oo_h[lo]):int(oo_h[hi])]
+        assert tk_oracle.fnv1a(got) == tk_oracle.fnv1a(eids) and len(got) == len(eids)
+
+
 def test_invalid_utf8_without_validation_is_safe(eng_small):
     """Callers that skip validation and pass malformed bytes get unspecified ids but no crash, no hang,
     and the id count stays within the documented bound (bytes + 2 per document)."""

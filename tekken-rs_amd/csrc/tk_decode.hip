@@ -244,12 +244,14 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     }
 }
 
-__device__ __forceinline__ bool tkd_is_boundary(const TkDecodeArgs& a, uint64_t p) {
-    return (a.run_bits[p >> 5] >> (p & 31)) & 1u;
-}
-
-// One wave per document, one lane per byte.  Same checks as tk_validate_kernel (RFC 3629) with the
-// extra rule that positions flagged in run_bits cut sequences.
+// One wave per document, 64 bytes per step, one lane per byte: the same checks as tk_validate_kernel (RFC 3629) with the
+// extra rule that positions flagged in run_bits cut sequences.  Everything a byte needs to know about its neighbours comes
+// from the wave (DPP shifts of the loaded bytes, ballots of the lead / continuation classes, the step's 64 boundary bits from
+// three uniform loads): a LEAD byte checks the bytes it claims, a continuation byte only that some lead claimed it.  A step
+// advances 58 bytes: leads are judged in lanes 0..60 (their up to three continuation bytes are in the window), continuation
+// bytes in lanes 3..60 (every lead that could claim them is a judged lane of the window) -- from lane 0 in the first step of
+// a document; the lanes 58..63 of a step are the lanes 0..5 of the next one.
+// (The first form let every byte >= 0x80 look around with its own global loads: 16 of the 21 ms of a C3 decode.)
 __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
@@ -259,34 +261,55 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
         if (a.doc_hi[d] == 0u) continue;            // the emit kernel saw only ASCII bytes: always valid
         const uint64_t s0 = a.out_offs[d], s1 = a.out_offs[d + 1];
         bool err = false;
-        for (uint64_t p = s0 + (uint64_t)lane; p < s1; p += 64) {
-            const uint32_t b0 = b[p];
-            if (b0 < 0x80u) continue;
-            if ((b0 & 0xC0u) == 0x80u) {
-                // continuation: a lead that covers it must sit within 3 bytes, with no boundary in (lead, p]
-                bool ok = false;
-                for (uint32_t k = 1; k <= 3 && p >= s0 + k; ++k) {
-                    if (tkd_is_boundary(a, p - k + 1)) break;
-                    const uint32_t q = b[p - k];
-                    if ((q & 0xC0u) == 0x80u) continue;
-                    const uint32_t need = q >= 0xF0u ? 3u : q >= 0xE0u ? 2u : q >= 0xC0u ? 1u : 0u;
-                    ok = need >= k;
-                    break;
+        // (the loads of a step are issued one step ahead: a step is short, and its one round trip was all a wave waited for)
+        uint32_t nb0 = s0 + (uint64_t)lane < s1 ? (uint32_t)b[s0 + lane] : 0u;
+        uint32_t nw0 = a.run_bits[s0 >> 5], nw1 = a.run_bits[(s0 >> 5) + 1], nw2 = a.run_bits[(s0 >> 5) + 2];
+        for (uint64_t p0 = s0; p0 < s1; p0 += 58) {
+            const uint64_t p = p0 + (uint64_t)lane;
+            const bool in = p < s1;
+            const uint32_t b0 = nb0;                                // (past the end: ASCII NUL, which claims nothing and needs nothing)
+            // (the same three words in every lane: on the scalar unit from here)
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw0), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw1),
+                           w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw2);
+            {
+                const uint64_t q0 = p0 + 58;
+                if (q0 < s1) {
+                    nb0 = q0 + (uint64_t)lane < s1 ? (uint32_t)b[q0 + lane] : 0u;
+                    nw0 = a.run_bits[q0 >> 5]; nw1 = a.run_bits[(q0 >> 5) + 1]; nw2 = a.run_bits[(q0 >> 5) + 2];
                 }
-                if (!ok) err = true;
-                continue;
             }
+            // the bytes at p + 1 .. p + 3 (lanes past the window end read 0: such a lead is judged in the next step)
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0x130, 0xF, 0xF, false);   // wave_shl:1
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b1, 0x130, 0xF, 0xF, false);
+            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b2, 0x130, 0xF, 0xF, false);
+            // boundary bits of the positions p0 .. p0 + 63 (bit k: a run starts at p0 + k)
+            const uint32_t sh = (uint32_t)(p0 & 31u);
+            const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            const uint64_t BND = sh ? ((lo64 >> sh) | ((uint64_t)w2 << (64u - sh))) : lo64;
+            const bool cont = in && (b0 & 0xC0u) == 0x80u;
+            const bool lead = in && b0 >= 0xC0u;
             const uint32_t need = b0 >= 0xF8u ? 99u : b0 >= 0xF0u ? 3u : b0 >= 0xE0u ? 2u : b0 >= 0xC2u ? 1u : 99u;
-            if (need == 99u || p + need >= s1) { err = true; continue; }
-            bool cut = false;
-            for (uint32_t k = 1; k <= need; ++k) cut |= tkd_is_boundary(a, p + k) || (b[p + k] & 0xC0u) != 0x80u;
-            if (cut) { err = true; continue; }
-            const uint32_t b1 = b[p + 1];
-            if (b0 == 0xE0u && b1 < 0xA0u) err = true;   // overlong 3-byte
-            if (b0 == 0xEDu && b1 >= 0xA0u) err = true;  // surrogates
-            if (b0 == 0xF0u && b1 < 0x90u) err = true;   // overlong 4-byte
-            if (b0 == 0xF4u && b1 >= 0x90u) err = true;  // > U+10FFFF
-            if (b0 > 0xF4u) err = true;
+            bool lead_ok = false;
+            if (lead && lane <= 60) {
+                lead_ok = need != 99u && p + need < s1;
+                if (lead_ok) {
+                    const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
+                    lead_ok = c1 && (need < 2u || c2) && (need < 3u || c3);
+                    const uint64_t cut = (BND >> (lane + 1)) & ((1ull << need) - 1ull);     // a run starts inside the sequence
+                    if (cut) lead_ok = false;
+                    if (b0 == 0xE0u && b1 < 0xA0u) lead_ok = false;   // overlong 3-byte
+                    if (b0 == 0xEDu && b1 >= 0xA0u) lead_ok = false;  // surrogates
+                    if (b0 == 0xF0u && b1 < 0x90u) lead_ok = false;   // overlong 4-byte
+                    if (b0 == 0xF4u && b1 >= 0x90u) lead_ok = false;  // > U+10FFFF
+                    if (b0 > 0xF4u) lead_ok = false;
+                }
+                if (!lead_ok) err = true;
+            }
+            // the positions the valid leads of this window claim
+            const uint64_t L1 = __ballot(lead_ok), L2 = __ballot(lead_ok && need >= 2u), L3 = __ballot(lead_ok && need >= 3u);
+            const uint64_t claimed = (L1 << 1) | (L2 << 2) | (L3 << 3);
+            // (in a later step the lanes 0..2 were judged as lanes 58..60 of the step before)
+            if (cont && lane <= 60 && (lane >= 3 || p0 == s0) && !((claimed >> lane) & 1ull)) err = true;
         }
         if (__ballot(err) && lane == 0) atomicMin(a.err + 2, (unsigned long long)d);
     }

@@ -120,3 +120,44 @@ def test_full_size_round_trip_device_resident(tk, bench_vocab):
     assert torch.equal(out_offs, d_offs)
     assert e.last_timing()["pipeline_ms"] > 0
     e.close()
+
+
+def test_utf8_validation_at_every_window_offset(tk, eng, test_vocab):
+    """tk_decode_validate_kernel judges 64 bytes per step with windows that overlap by six: every kind of sequence -- valid
+    2 / 3 / 4-byte code points, a lone continuation byte, a truncated lead, overlong forms, a surrogate, a code point beyond
+    U+10FFFF, a special token inside a code point (two runs, each invalid alone) -- at every offset 0..130 of a document, so
+    that each straddles the window seams in every way; the failing document is the one python's own decoder rejects."""
+    ns = test_vocab["num_special"]
+    P = tk.SpecialTokenPolicy
+
+    def byte_ids(bs):
+        return [ns + x for x in bs]
+
+    valid = ["é".encode(), "中".encode(), "\U0001f680".encode(), "é中\U0001f680".encode()]
+    docs = []
+    for k in range(0, 131):
+        for v in valid:
+            docs.append(byte_ids(b"a" * k + v + b"b" * 70 + v))
+    texts = eng.decode_docs(docs, P.Ignore)
+    assert all(t == bytes(x - ns for x in ids) for t, ids in zip(texts, docs))
+    bad = [bytes([0x80]), bytes([0xC3]), bytes([0xE4, 0xB8]), bytes([0xF0, 0x9F, 0x9A]), bytes([0xC0, 0xAF]), bytes([0xE0, 0x80, 0xAF]),
+           bytes([0xED, 0xA0, 0x80]), bytes([0xF4, 0x90, 0x80, 0x80]), bytes([0xF8, 0x88, 0x80, 0x80]), bytes([0xE4, 0xB8, 0x41]),
+           bytes([0xC3, 0xC3, 0xA9])]
+    filler = [byte_ids(("zé中" * 40).encode()) for _ in range(5)]
+    for k in list(range(0, 131, 1)):
+        for bseq in bad[k % 3::3]:                       # (a third of the kinds per offset: every kind meets every residue of 58)
+            raw = b"a" * k + bseq + b"b" * 9
+            with pytest.raises(UnicodeDecodeError):
+                raw.decode("utf-8")
+            batch = filler[:3] + [byte_ids(raw)] + filler[3:]
+            with pytest.raises(tk.TokenizerError) as e:
+                eng.decode_docs(batch, P.Ignore)
+            assert e.value.kind == "Tokenizers" and e.value.bad_doc == 3, (k, bseq)
+        # a special id between the bytes of a code point: two runs, each invalid on its own (src/tekkenizer.rs:552-555)
+        ids = byte_ids(b"a" * k) + [ns + 0xE4, ns + 0xB8, 1, ns + 0xAD] + byte_ids(b"b" * 9)
+        with pytest.raises(tk.TokenizerError) as e:
+            eng.decode_docs(filler[:2] + [ids], P.Ignore)
+        assert e.value.kind == "Tokenizers" and e.value.bad_doc == 2, k
+        # ... and the same bytes without the special id are fine
+        ok = byte_ids(b"a" * k) + [ns + 0xE4, ns + 0xB8, ns + 0xAD] + byte_ids(b"b" * 9)
+        assert eng.decode_docs([ok], P.Ignore) == [b"a" * k + "中".encode() + b"b" * 9]

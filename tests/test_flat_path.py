@@ -117,6 +117,27 @@ def test_emu_flat_long_pieces_stay_on_the_flat_path(test_vocab):
         _emu_check(test_vocab, docs, bos, eos)
 
 
+def test_emu_long_records_on_adversarial_vocabularies():
+    """The two merges behind the long-piece records -- 128-entry LDS columns (65..128 bytes), parts in registers (129..256) --
+    on vocabularies built to hurt (random multi-byte tokens in random rank order over tiny alphabets: chains that undercut,
+    runs of equal pairs), pieces of every length 65..256, against the oracle."""
+    import random
+    import gen_golden_merge as gg
+    rng = random.Random(77)
+    for alphabet, n_extra, max_len in (("ab", 60, 6), ("abc", 250, 5), ("aé中", 90, 4)):
+        toks = gg.vocab_adversarial(rng, alphabet, n_extra, max_len)
+        v = {"tokens": toks, "num_special": 5, "bos": 1, "eos": 2}
+        docs = []
+        for n in range(65, 257, 3):
+            w = "".join(rng.choice(alphabet) for _ in range(n))
+            while len(w.encode()) > 256:
+                w = w[:-1]
+            docs.append(b"x " + w.encode() + b" y")
+            docs.append((rng.choice(alphabet) * (n // 2) + w)[:120].encode() + b"\n" + w.encode()[:200].decode("utf-8", "ignore").encode())
+        flagged = _emu_check(v, docs, check_split=False)
+        assert len(flagged) < len(docs) // 2        # (most of them stay on the flat path: the records are what is tested)
+
+
 def test_emu_flat_handback_and_mixed(test_vocab):
     docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120)
     flagged = _emu_check(test_vocab, docs)

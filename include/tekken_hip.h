@@ -97,6 +97,10 @@ uint64_t tk_round_path_docs(const tk_ctx* ctx);
  * handing their documents to the per-document kernels (diagnostics / tests; TK_FLAT_LONG=0 at context creation switches
  * the path off, TK_FLAT_LONG128=0 its one-lane-per-piece merge). */
 uint64_t tk_long_piece_records(const tk_ctx* ctx);
+/* 2048-byte regions of the LAST batch that held a piece of more than 64 bytes and went through the CUT instantiation of the
+ * flat kernel (csrc/tk_flat_impl.h step 4b: such a piece is cut into fragments wherever no vocabulary token can span the
+ * boundary, and the fragments merge independently -- exact; diagnostics / tests; TK_FLAT_CUT=0 switches the cuts off). */
+uint64_t tk_cut_chunks(const tk_ctx* ctx);
 
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference

@@ -112,6 +112,9 @@ def lib():
     L.tk_round_path_docs.argtypes = [vp]
     L.tk_long_piece_records.restype = ctypes.c_uint64
     L.tk_long_piece_records.argtypes = [vp]
+    if hasattr(L, "tk_cut_chunks"):   # (diagnostics only; tools/ab_bench.sh also loads libraries built before it existed)
+        L.tk_cut_chunks.restype = ctypes.c_uint64
+        L.tk_cut_chunks.argtypes = [vp]
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
@@ -330,6 +333,10 @@ class Engine:
     def long_piece_records(self):
         """Pieces of 65..256 bytes of the last batch that stayed on the flat path as records."""
         return int(lib().tk_long_piece_records(self._h))
+
+    def cut_chunks(self):
+        """Regions of the last batch whose long pieces were cut into independently merged fragments."""
+        return int(lib().tk_cut_chunks(self._h)) if hasattr(lib(), "tk_cut_chunks") else 0
 
     def small_path_calls(self):
         """Calls served by the one-launch small-batch path so far."""

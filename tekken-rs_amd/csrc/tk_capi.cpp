@@ -112,6 +112,10 @@ struct tk_ctx {
     TkHostTables host;
     TkTablesView dview;
     DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_pairf, t_blob, t_offs, t_spblob, t_spoffs, t_uc2a, t_uc2b;
+    DevBuf t_cutk2, t_cutg3;       // the cut rule's bit maps (tk_tables.cpp make_cut_tables)
+    DevBuf f_cut;                  // flat path: chunks left to the CUT instantiation (tk_flat_cut_kernel)
+    void* cut_ctl_ptr = nullptr;   // what the control words at counters + 19 describe
+    bool no_flat_cut = false;      // TK_FLAT_CUT=0: no cut decomposition (pieces of more than 256 bytes hand their documents back; A / B and tests)
     int pattern = 0;               // tk_ctx_set_pattern: 0 the reference's hard-coded pattern, 1 the JSON pattern (row f-3)
     bool have_specials = false;
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
@@ -129,6 +133,7 @@ struct tk_ctx {
     int pipeline_forced = 0;       // TK_PIPELINE: 0 / 1 flat (default), 2 per-document kernels only
     uint64_t n_flagged = 0;
     uint64_t n_long_recs = 0;      // pieces of 65..TKF_LONGCAP bytes the flat path kept (last call)
+    uint64_t n_cut_chunks = 0;     // regions that went through the CUT instantiation (last call)
     void* long_ctl_ptr = nullptr;  // what the control words at counters + 16 describe
     uint32_t long_ctl_cap = 0;
     bool no_flat_long128 = false;  // TK_FLAT_LONG128=0: every long-piece record takes the single-wave merge
@@ -225,6 +230,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
         (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
         (rc = upload(c, c->t_pairf, h.pair_filter.data(), h.pair_filter.size() * 4)) ||
+        (rc = upload(c, c->t_cutk2, h.cut_k2.data(), h.cut_k2.size() * 4)) ||
+        (rc = upload(c, c->t_cutg3, h.cut_g3.data(), h.cut_g3.size() * 4)) ||
         (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())) ||
         (rc = upload(c, c->t_offs, h.offs.data(), h.offs.size() * 4)))
         return fail(rc);
@@ -239,12 +246,14 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
     c->dview.pair2 = (const uint32_t*)c->t_pair2.p;
     c->dview.pair_filter = (const uint32_t*)c->t_pairf.p;
+    c->dview.cut_k2 = (const uint32_t*)c->t_cutk2.p;
+    c->dview.cut_g3 = (const uint32_t*)c->t_cutg3.p;
     c->dview.blob = (const uint8_t*)c->t_blob.p;
 
     if (c->counters.reserve(128) != hipSuccess) { c->err = "hipMalloc(counters) failed"; return fail(TK_ERR_RUNTIME); }
     // the wave primitives (DPP wave shifts, bpermute) are checked once on the real device
     uint32_t bad = 1;
-    if (hipMemsetAsync(c->counters.p, 0, 64, c->stream) != hipSuccess ||
+    if (hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess ||   // (counters 0..15 and the control words behind them)
         tk_launch_wave_selftest((uint32_t*)c->counters.p, c->stream) != hipSuccess ||
         hipMemcpyAsync(&bad, c->counters.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -257,6 +266,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     }
     if (const char* fl = getenv("TK_FLAT_LONG")) c->no_flat_long = atoi(fl) == 0;
     if (const char* fl = getenv("TK_FLAT_LONG128")) c->no_flat_long128 = atoi(fl) == 0;
+    if (const char* fl = getenv("TK_FLAT_CUT")) c->no_flat_cut = atoi(fl) == 0;
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
     if (const char* lz = getenv("TK_LONG_LAZY_MUL")) c->long_lazy_mul = (uint32_t)atoi(lz);
     if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
@@ -269,7 +279,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
+    DevBuf* bufs[] = {&c->t_cutk2, &c->t_cutg3, &c->f_cut, &c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->t_inline, &c->t_len8,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
@@ -515,6 +525,22 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
             c->long_ctl_ptr = c->f_long.p;
             c->long_ctl_cap = fa.long_cap;
         }
+        // the list of the chunks that hold a piece of more than 64 bytes (counter 12, control words 19..20): the flat kernel
+        // leaves them to tk_flat_cut_kernel (TK_FLAT_CUT=0: a null list, no cuts)
+        void* want_cut = nullptr;
+        if (!c->no_flat_cut && c->pattern == 0) {
+            TK_HIP(c, c->f_cut.reserve((n_chunks + 1) * 4));
+            want_cut = c->f_cut.p;
+            fa.cut_list = (uint32_t*)c->f_cut.p;
+            fa.cut_count = (const uint32_t*)c->counters.p + 12;
+        }
+        if (c->cut_ctl_ptr != want_cut) {
+            const uint64_t pv = (uint64_t)reinterpret_cast<uintptr_t>(want_cut);
+            const uint32_t ctl[2] = {(uint32_t)pv, (uint32_t)(pv >> 32)};
+            TK_HIP(c, hipMemcpyAsync((uint32_t*)c->counters.p + 19, ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
+            TK_HIP(c, hipStreamSynchronize(s));
+            c->cut_ctl_ptr = want_cut;
+        }
     }
 
     // One host sync per batch in the common case.  Everything that depends on device-side counts stays on the device:
@@ -555,10 +581,10 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, hipEventRecord(c->ev[2], s));
         // counters 4 (handed-back documents), 6..7 (total ids, left there by the assembly) and 11 (long-piece records): one
         // copy into pinned memory
-        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 48, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 52, hipMemcpyDeviceToHost, s));
         TK_HIP(c, hipStreamSynchronize(s));
         memcpy(&total, c->h_pin + 6, 8);
-        if (!final_pass) { n_todo = c->h_pin[4]; n_lrec = c->h_pin[11]; }
+        if (!final_pass) { n_todo = c->h_pin[4]; n_lrec = c->h_pin[11]; c->n_cut_chunks = c->h_pin[12]; }
         return TK_OK;
     };
     int rc = finish(0);
@@ -1096,6 +1122,7 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
 extern "C" uint64_t tk_small_path_calls(const tk_ctx* c) { return c ? c->n_small_calls : 0; }
 extern "C" uint64_t tk_round_path_docs(const tk_ctx* c) { return c ? c->n_round_docs : 0; }
 extern "C" uint64_t tk_long_piece_records(const tk_ctx* c) { return c ? c->n_long_recs : 0; }
+extern "C" uint64_t tk_cut_chunks(const tk_ctx* c) { return c ? c->n_cut_chunks : 0; }
 
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;

@@ -97,6 +97,34 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_dbg_kernel(TkFlatAr
     else tk_flat_kernel_body<1, 1>(a, lds_all);
 }
 
+// The chunks tk_flat_kernel left alone because they hold a piece of more than 64 bytes (a.cut_list): the same chunk work
+// with the CUT step -- such pieces are cut into fragments wherever no vocabulary token can span the boundary
+// (tk_flat_impl.h step 4b), so that a 32 KiB letter run becomes thousands of independent short merges instead of one chain
+// and its document stays on the flat path.  Persistent waves over the list; the count never leaves the device.
+template <int DBG>
+__device__ __forceinline__ void tk_flat_cut_body(const TkFlatArgs& a, uint32_t* lds_all) {
+    const uint32_t n = *a.cut_count;
+    if (n == 0u) return;                                     // (grid-uniform)
+    const int lane = wv_lane();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* lds = lds_all + wv * TKF_LDS_WORDS_CUT;
+    tk_flat_init_lds(a, lds, lane);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKF_BLOCK / 64);
+    for (uint64_t i = (uint64_t)blockIdx.x * (TKF_BLOCK / 64) + wv; i < n; i += n_waves) {
+        const uint64_t c = (uint64_t)__builtin_amdgcn_readfirstlane((int)a.cut_list[i]);
+        if (a.t.key_hash_mode == 0u) tk_flat_chunk<DBG, 0, 0, 1>(a, c, lane, lds);
+        else tk_flat_chunk<DBG, 1, 0, 1>(a, c, lane, lds);
+    }
+}
+__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS_CUT];
+    tk_flat_cut_body<0>(a, lds_all);
+}
+__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_dbg_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS_CUT];
+    tk_flat_cut_body<1>(a, lds_all);
+}
+
 // wave w of tk_merge_kernel starts with item 64 w of the narrow classes, wave w of tk_merge_wide_kernel with item 64 w of
 // the wide ones: note down which sub-queue holds it (thread e owns the waves whose first item falls into sub-queue e), so
 // that the merge waves do not have to search the prefix sums
@@ -421,6 +449,11 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    if (a.cut_list && a.pattern == 0) {
+        // the chunks with a piece of more than 64 bytes (none on ordinary text: the blocks read a zero and leave)
+        if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_cut_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(tk_flat_cut_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    }
     return hipGetLastError();
 }
 

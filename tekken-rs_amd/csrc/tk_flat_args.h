@@ -15,12 +15,15 @@
 #define TKF_LONGCAP 256u                             /* a piece of 65..LONGCAP bytes keeps its document on the flat path (tk_flat_long_kernel) */
 #define TKF_STRIDE (TKF_COMMIT + 64 + TKF_LONGCAP)   /* id slots per chunk: a piece may reach 63 bytes past the commit range, and the
                                                         chunk's last piece, when its end is not in the region, reserves LONGCAP slots */
-/* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes) */
+/* queue records per chunk, one sub-queue per length class (2..8, 9..16, 17..32, 33..64 bytes).  A chunk owns the pieces that
+   start in its commit range and, where a long piece that it cuts into fragments ends in its right halo, the fragments up to
+   that end (tk_flat_impl.h, CUT instantiation): TKF_OWN bytes at most */
+#define TKF_OWN (TKF_COMMIT + TKF_HR)
 #define TKF_MISSOFF0 0u
-#define TKF_MISSOFF1 (TKF_COMMIT / 2u)                              /* at most COMMIT / 2 pieces of >= 2 bytes */
-#define TKF_MISSOFF2 (TKF_MISSOFF1 + (TKF_COMMIT + 8u) / 9u)
-#define TKF_MISSOFF3 (TKF_MISSOFF2 + (TKF_COMMIT + 16u) / 17u)
-#define TKF_MISSCAP ((TKF_MISSOFF3 + (TKF_COMMIT + 32u) / 33u + 7u) & ~7u)
+#define TKF_MISSOFF1 (TKF_OWN / 2u)                                 /* at most OWN / 2 pieces of >= 2 bytes */
+#define TKF_MISSOFF2 (TKF_MISSOFF1 + (TKF_OWN + 8u) / 9u)
+#define TKF_MISSOFF3 (TKF_MISSOFF2 + (TKF_OWN + 16u) / 17u)
+#define TKF_MISSCAP ((TKF_MISSOFF3 + (TKF_OWN + 32u) / 33u + 7u) & ~7u)
 /* queue record: position in the region | length << POSBITS | id slot << (POSBITS + 7) */
 #if TKF_W == 32
 #define TKF_POSBITS 11
@@ -38,9 +41,12 @@ struct TkFlatLongRec {
     uint64_t pos;        // first byte of the piece in the packed stream
     uint32_t chunk;      // owning chunk: its ids go to tmp[chunk * TKF_STRIDE + slot ..]
     uint32_t slot;
-    uint32_t len;        // bytes of the piece; 0: the end lies beyond the chunk's region (the sequential matcher finds it)
+    uint32_t len;        // bytes of the piece; 0: the end lies beyond the chunk's region (the sequential matcher finds it);
+                         // bit 31 (TKF_LREC_FRAG): a FRAGMENT of a cut piece -- merged without the whole-piece look-up
     uint32_t reserved;   // id slots reserved for it: len, or TKF_LONGCAP when the end was not seen
 };
+
+#define TKF_LREC_FRAG 0x80000000u
 
 struct TkFlatArgs {
     const uint8_t* bytes;        // packed text of all documents
@@ -64,9 +70,13 @@ struct TkFlatArgs {
     int long_merge128;           // records of 65..128 bytes that are no vocabulary keys are marked for tk_flat_long128_kernel (one lane per
                                  // piece); 0: the single-wave merge takes them too
     const uint32_t* long_ctl;    // what the flat kernel reads, in its rare path only, so that the three values above cost it no
-                                 // scalar registers: device words {long_recs lo, hi, long_cap}, the record counter five words
-                                 // BELOW them (the context's counter block: counter 11, control words at 16..18).  NULL: a piece
-                                 // of more than 64 bytes hands its document back
+                                 // scalar registers: device words {long_recs lo, hi, long_cap, cut_list lo, hi}, the record counter
+                                 // five words BELOW them and the cut-chunk counter four words below (the context's counter block:
+                                 // counters 11 and 12, control words at 16..20).  NULL: a piece of more than 64 bytes hands its
+                                 // document back
+    uint32_t* cut_list;          // [n_chunks] chunks with a piece of more than 64 bytes: left by tk_flat_kernel to the CUT instantiation
+                                 // (tk_flat_cut_kernel), which cuts such pieces into fragments where no token can span (NULL: no cuts)
+    const uint32_t* cut_count;   // entries of cut_list (device counter 12)
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
     int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,

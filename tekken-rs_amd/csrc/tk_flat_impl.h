@@ -71,6 +71,8 @@
                                                         v_readlane, a VALU slot each, and VALU issue is what bounds it); an LDS
                                                         broadcast read costs an LDS slot, of which it has plenty */
 #define TKF_LDS_WORDS (TKF_L_CONST + 8)
+#define TKF_L_FS TKF_LDS_WORDS                       /* [64] CUT instantiation only: cut-only piece starts (fragments begin / end there) */
+#define TKF_LDS_WORDS_CUT (TKF_LDS_WORDS + 64)
 
 
 // ------------------------------------------------------------------------------------------
@@ -442,8 +444,12 @@ TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n)
 // flags of tk_split_batch: every one of those tests costs scalar registers and VALU slots the kernel does not have.
 // MODE = the key hash the tables were built with (TkTablesView::key_hash_mode), a compile-time constant here.
 // PAT = 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in).
-template <int DBG, int MODE, int PAT = 0>
-TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
+// CUT = 0: the production instantiation; a chunk that holds a piece of more than 64 bytes (two neighbouring lanes without a
+// piece start) is appended to a.cut_list and left untouched -- the function returns true.  CUT = 1 (tk_flat_cut_kernel, over
+// that list): the same chunk work, and pieces of more than 64 bytes are cut into FRAGMENTS wherever the vocabulary rules out a
+// part that spans the boundary (step 4b); fragments merge on their own, without the whole-piece look-up.
+template <int DBG, int MODE, int PAT = 0, int CUT = 0>
+TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
     const int64_t n = (int64_t)a.n_bytes;
     const int64_t c0 = (int64_t)c * TKF_COMMIT, r0 = c0 - TKF_HL, r1 = r0 + TKF_REGION;
@@ -470,6 +476,8 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         for (int k = 0; k < TKF_W / 4; ++k) txt[k] = x[k];
         if (lane == 0) for (int k = 0; k < 4; ++k) lds[TKF_L_TXT + TKF_REGION / 4 + k] = 0u;
     }
+    uint32_t nextb = 0;                                     // CUT: the byte behind the region (the last lane's trigram reaches it)
+    if (CUT && r1 < n) nextb = (uint32_t)a.bytes[r1];
     TkfClass m = tkf_classify(x);
     if (tkf_any(m.HI)) {
         // multi-byte code points: every lane walks the lead bytes among its own bytes, decodes the code point, looks its
@@ -551,7 +559,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             a.kcount[c] = v == 0xFFFFFFFFu ? 1u : 0u;
             for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
         }
-        return;
+        return false;
     }
 
     // ---- 2. document starts inside the region -> DS (lane layout, through LDS) ------------------
@@ -578,13 +586,34 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
 
     // ---- 3. piece starts ---------------------------------------------------------------------------
     uint32_t SPR, cont;
-    const uint32_t PS = PAT ? tkf_rules_json(m, DS, lane, &SPR, &cont) : tkf_rules(m, DS, lane, &SPR, &cont);
+    uint32_t PS = PAT ? tkf_rules_json(m, DS, lane, &SPR, &cont) : tkf_rules(m, DS, lane, &SPR, &cont);
     if (DBG && (a.dbg_ablate & 8)) {
         if (lane == 0) {
             a.kcount[c] = (PS + SPR + cont) == 0xFFFFFFFFu ? 1u : 0u;
             for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
         }
-        return;
+        return false;
+    }
+    if (!CUT && !PAT) {
+        // A piece of more than 64 bytes (surely one of 96 and more, and any piece that begins or goes on beyond this region)
+        // leaves two neighbouring lanes of the commit range / right halo without a piece start: the chunk is left to the CUT
+        // instantiation.  Both chunks of a piece that crosses a commit boundary decide alike: the one it starts in sees no
+        // start in its right halo (lanes 62, 63), the next one none in its first 64 commit bytes (lanes 2, 3).
+        const uint64_t Zm = wv_ballot(PS == 0u) & ~(((uint64_t)1 << TKF_NHL) - 1ull);
+        if (TKF_W == 32 && (Zm & (Zm >> 1))) {
+            const uint64_t lc = (uint64_t)wv_first(lds[TKF_L_CONST + 6]) | ((uint64_t)wv_first(lds[TKF_L_CONST + 7]) << 32);
+            if (lc != 0ull) {
+                const uint32_t* ctl = reinterpret_cast<const uint32_t*>(wv_global_ptr(lc));
+                const uint64_t lp = (uint64_t)wv_first(ctl[3]) | ((uint64_t)wv_first(ctl[4]) << 32);
+                if (lp != 0ull) {
+                    if (lane == 0) {
+                        const uint32_t q = wv_atomic_add(const_cast<uint32_t*>(ctl) - 4, 1u);
+                        reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(wv_global_ptr(lp)))[q] = (uint32_t)c;
+                    }
+                    return true;
+                }
+            }
+        }
     }
     // bits of the commit range [ca, cb): whole lanes 2..59 for every chunk but the last one of the stream
     uint32_t commit_mask = (uint32_t)(lane - TKF_NHL) < (uint32_t)(TKF_COMMIT / TKF_W) ? TKF_WM : 0u;
@@ -644,10 +673,77 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
     }
 
+    // ---- 4b. CUT instantiation: pieces of more than 64 bytes are cut into fragments -------------------------------
+    // (tools/cut_model.py.)  The merge loop joins two parts only if their bytes are a vocabulary key, so a part that spans
+    // the boundary between bytes i-1 and i is a key that contains b[i-1] b[i] there: the bigram itself, or a longer key
+    // that holds the trigram b[i-2..i] or b[i-1..i+1].  Where the vocabulary has neither (cut_k2: two-byte keys; cut_g3:
+    // trigrams inside tokens) no part ever spans the boundary and both sides merge on their own, in their own order:
+    // position i becomes a piece start.  A piece with a cut is no key (its n-grams would occur in a token: itself), so its
+    // FRAGMENTS skip the whole-piece look-up -- and must: what merging a fragment gives need not be the key it may happen
+    // to be.  Which pieces: those of more than 64 bytes that start in the commit range (S64: 64 bytes without a start behind
+    // them; that includes a piece whose end this region does not see) and the piece that comes in from the last chunk when
+    // it covers the first 64 commit bytes -- exactly when that chunk saw no end of it.  A cut is a pure function of four
+    // bytes, so the chunks of a piece agree on every fragment; a chunk owns the fragments that start in its commit range
+    // and, when the piece ends in its right halo, those up to that end (the next chunk sees fewer than 64 foreign bytes
+    // and leaves them alone).
+    uint32_t own_mask = commit_mask;
+    uint32_t FS = 0;                                        // cut-only piece starts
+    if (CUT) {
+        const uint32_t R1 = lane >= TKF_NHL ? (~PS & TKF_WM) : 0u;
+        uint32_t F = R1 & tkf_shr(R1, 1);                   // F(i): no start at i .. i + 2^k - 1
+        F &= tkf_shr(F, 2);
+        F &= tkf_shr(F, 4);
+        F &= tkf_shr(F, 8);
+        F &= tkf_shr(F, 16);
+        F &= wv_up1(F);                                     // ... i + 63 (the bit 32 positions on is the next lane's)
+        const uint32_t S64 = PS & commit_mask & tkf_shr(F, 1);
+        uint32_t LM = 0;                                    // bytes of the pieces that are cut (behind their first byte)
+        if (tkf_any(S64)) LM = tkf_ripple(R1, tkf_shl(S64, 1) & R1);
+        // the piece that comes in from the chunk before: up to the first start at or behind the commit start
+        uint32_t f_lo = TKF_REGION;
+        {
+            const uint64_t Bm = wv_ballot(lane >= TKF_NHL && PS != 0u);
+            if (Bm) {
+                const int fl = tk_ctz64(Bm);
+                f_lo = (uint32_t)TKF_W * (uint32_t)fl + (uint32_t)__builtin_ctz(wv_readlane(PS, fl));
+            }
+        }
+        if (f_lo >= (uint32_t)ca + 64u) {
+            const int lo = ca - TKF_W * lane, hi = (int)f_lo - TKF_W * lane;
+            LM |= tkf_lowmask32(hi < 0 ? 0 : hi) & ~tkf_lowmask32(lo < 0 ? 0 : lo);
+        }
+        const uint32_t ge_cb = ~tkf_lowmask32(cb - TKF_W * lane < 0 ? 0 : cb - TKF_W * lane);
+        const bool closed = tkf_any(PS & ge_cb);            // the piece that crosses the commit end ends inside the region
+        // where a cut is wanted: T(j) = the trigram around byte j occurs inside a token, K(j) = bytes j-1, j are a key
+        const uint32_t need = LM | tkf_shr(LM, 1);
+        uint32_t TG = 0, K2 = 0;
+        {
+            const uint32_t prevb = wv_dn1(x[TKF_W / 4 - 1]) >> 24;
+            uint32_t nb = wv_up1(x[0]) & 0xFFu;
+            if (lane == 63) nb = nextb;
+            if (need) {
+                uint32_t b0 = prevb, b1 = x[0] & 0xFFu;
+                for (int k = 0; k < TKF_W; ++k) {
+                    const uint32_t b2 = k + 1 < TKF_W ? (x[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu : nb;
+                    if ((need >> k) & 1u) {
+                        const uint32_t i3 = b0 | (b1 << 8) | (b2 << 16), i2 = b0 | (b1 << 8);
+                        TG |= ((a.t.cut_g3[i3 >> 5] >> (i3 & 31u)) & 1u) << k;
+                        K2 |= ((a.t.cut_k2[i2 >> 5] >> (i2 & 31u)) & 1u) << k;
+                    }
+                    b0 = b1; b1 = b2;
+                }
+            }
+        }
+        FS = LM & ~PS & ~K2 & ~TG & ~tkf_shl(TG, 1);
+        PS |= FS;
+        if (closed) own_mask |= LM & ge_cb;
+        lds[TKF_L_FS + lane] = FS;
+    }
+
     // ---- 5. enumerate the pieces: positions of the set bits of PS from the commit start on -------
     // One pass over all lanes when the pieces fit the LDS list (always with 16 bytes per lane; with 32 bytes per lane
     // unless the region averages under two bytes per piece); otherwise two passes, lanes below 32 and lanes from 32 on.
-    uint32_t PSown = PS & commit_mask;
+    uint32_t PSown = PS & own_mask;
     uint32_t PSlist = lane >= TKF_NHL ? PS : 0u;            // commit range and right halo (ends of the last pieces)
     uint32_t np_all, np_own, pfx_all, pfx_own;
     {
@@ -708,7 +804,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         lane_hi = pass ? 64 : 32;
         const bool mine = (uint32_t)lane >= lane_lo && (uint32_t)lane < lane_hi;
         PSlist = mine ? PS : 0u;
-        PSown = PSlist & commit_mask;
+        PSown = PSlist & own_mask;
         uint32_t tot;
         const uint32_t pf = tkf_scan_excl((uint32_t)__builtin_popcount(PSlist) | ((uint32_t)__builtin_popcount(PSown) << 16), lane, &tot);
         pfx_all = pf & 0xFFFFu; pfx_own = pf >> 16;
@@ -774,6 +870,15 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                                    h, kk[0], kk[1], kk[2], kk[3], len);
             }
         }
+        // CUT: a fragment (it begins or ends at a cut) takes no whole-piece look-up: a single byte is its own rank, anything
+        // longer goes to the merge queues as it is
+        bool frag = false;
+        if (CUT) {
+            const uint32_t pe = pos + len;
+            frag = act && ((((lds[TKF_L_FS + (pos >> TKF_LOGW)] >> (pos & (TKF_W - 1))) & 1u) != 0u) ||
+                           (pe < (uint32_t)TKF_REGION && ((lds[TKF_L_FS + (pe >> TKF_LOGW)] >> (pe & (TKF_W - 1))) & 1u) != 0u));
+            if (frag && len >= 2u) r = TK_RANK_MAX;
+        }
         bool toolong = false;
         if (wv_ballot(len > 16u)) {                         // rare: polynomial hash over the bytes, LONG table; > 64: see below
             uint32_t lres = 0;                              // a long piece that stays on the flat path: id slots reserved for it
@@ -785,9 +890,9 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 // the long kernel finds the end with the sequential matcher -- beyond LONGCAP it flags the document itself.
                 lopen = idx + 1u == np_all && sentinel == TKF_REGION && r0 + (int64_t)TKF_REGION < (int64_t)a.n_bytes;
                 const bool have_ctl = (lds[TKF_L_CONST + 6] | lds[TKF_L_CONST + 7]) != 0u;
-                if (!PAT && have_ctl && (lopen || len <= TKF_LONGCAP)) lres = lopen ? TKF_LONGCAP : len;
-                else toolong = true;
-            } else if (len > 16u && !(DBG && (a.dbg_ablate & 1))) {
+                if (!PAT && have_ctl && (lopen || len <= TKF_LONGCAP) && !(CUT && frag && lopen)) lres = lopen ? TKF_LONGCAP : len;
+                else toolong = true;                        // (a fragment whose end the region does not show: no cut in 64 bytes)
+            } else if (len > 16u && !(DBG && (a.dbg_ablate & 1)) && !(CUT && frag)) {
                 uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
                 for (uint32_t q = 0; q < len; ++q) {
                     const uint32_t b = rbytes[pos + q];
@@ -822,7 +927,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                     if (!longp) {
                     } else if (q < ctl[2]) {
                         TkFlatLongRec lr;
-                        lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = lslot; lr.len = lopen ? 0u : len; lr.reserved = lres;
+                        lr.pos = (uint64_t)(r0 + (int64_t)pos); lr.chunk = (uint32_t)c; lr.slot = lslot; lr.len = lopen ? 0u : (CUT && frag ? len | TKF_LREC_FRAG : len); lr.reserved = lres;
                         recs[q] = lr;
                     } else {                                // no room for the record: the document is handed back after all
                         wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
@@ -922,6 +1027,7 @@ TK_DEV void tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     wv_lds_sync();
     doc_outputs(true, anybad);
     wv_lds_sync();  // the next chunk reuses the LDS slice
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -944,7 +1050,9 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     ea.dbg_starts = nullptr; ea.dbg_mark = nullptr; ea.long_list = nullptr; ea.long_count = nullptr; ea.long_min = 0; ea.long_lazy_mul = 0; ea.long_force = 0;
     ea.long_jobs = nullptr; ea.long_job_count = nullptr; ea.long_job_cap = 0; ea.t = a.t;
     const uint64_t s1 = wv_first64(a.doc_offs[d + 1]);
-    const uint64_t e = lr.len ? g + lr.len : wv_first64(tk_match_end(a.t, a.bytes, g, s1));
+    const bool frag = (lr.len & TKF_LREC_FRAG) != 0u;       // a fragment of a cut piece: merged as it is, no whole-piece look-up
+    const uint32_t rlen = lr.len & ~TKF_LREC_FRAG;
+    const uint64_t e = rlen ? g + rlen : wv_first64(tk_match_end(a.t, a.bytes, g, s1));
     const uint32_t len = (uint32_t)(e - g);
     uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;
     if (e - g > (uint64_t)lr.reserved) {                    // an open piece of more than LONGCAP bytes: the per-document kernels take the document
@@ -952,7 +1060,7 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
         return;
     }
     uint32_t cur = 0;
-    const uint32_t r = tk_piece_lookup(ea, pw, lane, g, e);
+    const uint32_t r = frag ? TK_RANK_MAX : tk_piece_lookup(ea, pw, lane, g, e);
     if (r != TK_RANK_MAX) {
         if (lane == 0) out[0] = r + a.t.num_special;
         cur = 1;

@@ -104,6 +104,10 @@ TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
 #define TK_PAIRF_WORDS (1u << (TK_PAIRF_LOG2 - 5))
 TK_HD uint32_t tk_pair_fbit(uint32_t h) { return h >> (32 - TK_PAIRF_LOG2); }
 
+/* cut rule (tk_tables.cpp make_cut_tables): exact bit maps over byte bigrams / trigrams */
+#define TK_CUT_K2_WORDS (1u << 11)       /* 2^16 bits */
+#define TK_CUT_G3_WORDS (1u << 19)       /* 2^24 bits = 2 MB */
+
 TK_HD uint32_t tk_hash_alt(uint32_t h) { return (h << 16) | (h >> 16); }  /* second location: the other half of the bits */
 
 TK_HD uint64_t tk_pair_pack(uint32_t a, uint32_t b, uint32_t rank) {

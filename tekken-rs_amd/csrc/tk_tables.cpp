@@ -37,6 +37,26 @@ void TkHostTables::make_pair_filter() {
     }
 }
 
+// The cut rule (tk_flat_impl.h, CUT instantiation; model: tools/cut_model.py): a part of the merge loop that spans the
+// boundary between bytes i-1 and i is a vocabulary key -- of two bytes (then it is the bigram itself: cut_k2) or of more
+// (then it contains b[i-2..i] or b[i-1..i+1]: cut_g3 holds every trigram that occurs inside a token).
+void TkHostTables::make_cut_tables() {
+    cut_k2.assign(TK_CUT_K2_WORDS, 0u);
+    cut_g3.assign(TK_CUT_G3_WORDS, 0u);
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const uint8_t* p = blob.data() + offs[r];
+        const uint32_t len = offs[r + 1] - offs[r];
+        if (len == 2u) {
+            const uint32_t b = (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+            cut_k2[b >> 5] |= 1u << (b & 31u);
+        }
+        for (uint32_t i = 0; i + 3u <= len; ++i) {
+            const uint32_t b = (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16);
+            cut_g3[b >> 5] |= 1u << (b & 31u);
+        }
+    }
+}
+
 TkTablesView TkHostTables::host_view() const {
     TkTablesView v;
     v.uc_stage1 = uc_stage1.data();
@@ -49,6 +69,8 @@ TkTablesView TkHostTables::host_view() const {
     v.pair_tab = pair_tab.data();
     v.pair2 = pair2.data();
     v.pair_filter = pair_filter.data();
+    v.cut_k2 = cut_k2.data();
+    v.cut_g3 = cut_g3.data();
     v.blob = blob.data();
     v.key8_mask = key8_mask;
     v.key_mask = key_mask;
@@ -298,6 +320,7 @@ int tk_build_tables(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks,
         for (uint64_t b1 : spill) out.pair_tab[2 * b1] |= TK_PAIR_SPILL;   // (a bucket that spilled is full: its first entry is real)
     }
     out.make_pair_filter();
+    out.make_cut_tables();
     return TK_OK;
 }
 
@@ -396,6 +419,7 @@ bool tk_tables_load(TkHostTables& t, uint64_t key, const std::string& path) {
     x.uc2_stage1.assign(TK_UC2_STAGE1, TK_UC2_STAGE1 + TK_UC2_STAGE1_LEN);   // constant tables, not cached
     x.uc2_stage2.assign(TK_UC2_STAGE2, TK_UC2_STAGE2 + TK_UC2_STAGE2_LEN);
     x.make_pair_filter();
+    x.make_cut_tables();
     t = std::move(x);
     return true;
 }

@@ -25,6 +25,8 @@ struct TkTablesView {
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
     const uint32_t* pair_filter;     // [TK_PAIRF_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab (tk_hash.h)
+    const uint32_t* cut_k2;          // [TK_CUT_K2_WORDS] bit (b0 | b1 << 8): the two bytes are a vocabulary KEY (cut rule, tk_hash.h)
+    const uint32_t* cut_g3;          // [TK_CUT_G3_WORDS] bit (b0 | b1 << 8 | b2 << 16): the trigram occurs inside some token
     const uint8_t* blob;             // token bytes, for verifying LONG hits
     uint32_t key8_mask, key_mask, long_mask, pair_mask;
     uint32_t key_hash_mode;          // tk_key_hash mode the KEY table was built with
@@ -45,6 +47,7 @@ struct TkHostTables {
     std::vector<uint64_t> pair_tab;
     std::vector<uint32_t> pair2;
     std::vector<uint32_t> pair_filter;  // derived from pair_tab (make_pair_filter), not part of the table cache
+    std::vector<uint32_t> cut_k2, cut_g3;   // the cut rule's bit maps, derived from blob / offs (make_cut_tables), not part of the table cache
     uint32_t key8_mask = 0, key_mask = 0, long_mask = 0, pair_mask = 0, key_hash_mode = 0;
     uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
     uint32_t p1inv = 0, p2inv = 0;
@@ -52,6 +55,7 @@ struct TkHostTables {
 
     TkTablesView host_view() const;
     void make_pair_filter();
+    void make_cut_tables();
 };
 
 // Returns 0 on success; on failure returns a negative TK_ERR_* code and fills `err`.

@@ -2,6 +2,8 @@
 // TEST INFRASTRUCTURE ONLY; see tk_wave_emu.h.  Built into tests/emu/libtk_emu.so by
 // tests/emu/Makefile and loaded with ctypes from tests/test_kernel_emu.py.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -146,7 +148,15 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         ctlblk[16] = (uint32_t)pv; ctlblk[17] = (uint32_t)(pv >> 32); ctlblk[18] = fa.long_cap;
         fa.long_ctl = &ctlblk[16];
     }
-    std::vector<uint32_t> lds(TKF_LDS_WORDS, 0);
+    // chunks with a piece of more than 64 bytes are left to the CUT instantiation (counter 12, control words 19..20; TK_FLAT_CUT=0: no cuts)
+    std::vector<uint32_t> cut_list(n_chunks + 1, 0);
+    if (fa.long_ctl && !pattern && !(getenv("TK_FLAT_CUT") && atoi(getenv("TK_FLAT_CUT")) == 0)) {
+        const uint64_t pv = (uint64_t)reinterpret_cast<uintptr_t>(cut_list.data());
+        ctlblk[19] = (uint32_t)pv; ctlblk[20] = (uint32_t)(pv >> 32);
+        fa.cut_list = cut_list.data();
+        fa.cut_count = &ctlblk[12];
+    }
+    std::vector<uint32_t> lds(TKF_LDS_WORDS_CUT, 0);
     uint64_t ops = 0;
     if (n_chunks) {
         tkemu::run_wave([&](int lane) {
@@ -160,6 +170,20 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             }
         });
         ops += tkemu::g_wave->n_ops;
+        if (fa.cut_list && ctlblk[12]) {                    // tk_flat_cut_kernel
+            if (ctlblk[12] > n_chunks) { g_err = "cut list overflow"; return TK_ERR_RUNTIME; }
+            tkemu::run_wave([&](int lane) {
+                tk_flat_init_lds(fa, lds.data(), lane);
+                for (uint32_t i = 0; i < ctlblk[12]; ++i) {
+                    const uint64_t c = cut_list[i];
+                    const bool m1 = fa.t.key_hash_mode != 0u;
+                    if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1, 0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0, 0, 1>(fa, c, lane, lds.data()); }
+                    else { if (m1) tk_flat_chunk<0, 1, 0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<0, 0, 0, 1>(fa, c, lane, lds.data()); }
+                }
+            });
+            ops += tkemu::g_wave->n_ops;
+        }
+        if (getenv("TK_EMU_LOG")) fprintf(stderr, "[emu] chunks %llu, cut chunks %u, long records %u\n", (unsigned long long)n_chunks, ctlblk[12], ctlblk[11]);
         std::vector<uint64_t> mpfx(4 * n_chunks + 1, 0);
         for (uint64_t e = 0; e < 4 * n_chunks; ++e) mpfx[e + 1] = mpfx[e] + miss_count[e];
         fa.miss_prefix = mpfx.data();

@@ -87,11 +87,11 @@ def test_emu_flat_sparse_miss_queues(test_vocab):
     assert _emu_check(test_vocab, docs) == []
 
 
-def test_emu_flat_long_pieces_stay_on_the_flat_path(test_vocab):
+def test_emu_flat_long_pieces_stay_on_the_flat_path(test_vocab, monkeypatch):
     """Pieces of 65..256 bytes (tk_flat_impl.h step 6, tk_flat_long_wave): their documents are NOT handed back -- the piece
     becomes a record, its ids come from one wave's lookup / merge into the reserved slots; where the chunk does not see the
     end of its last piece (the piece crosses the region end) the sequential matcher finds it; beyond 256 bytes the document
-    is handed back after all.  Letter runs, CJK runs, punctuation runs, at every offset around a chunk boundary."""
+    is handed back after all unless the piece can be cut (step 4b; TK_FLAT_CUT=0 shows the hand-back).  Letter runs, CJK runs, punctuation runs, at every offset around a chunk boundary."""
     import random
     rng = random.Random(5)
     filler = b"ab cd ef gh ij kl mn op qr st uv wx yz " * 60                 # 2340 bytes of short pieces
@@ -111,10 +111,48 @@ def test_emu_flat_long_pieces_stay_on_the_flat_path(test_vocab):
         handed.append(b"x " + w + b" y")
         handed.append(filler[:1899] + w + b" z")
     docs = kept + handed
+    assert _emu_check(test_vocab, docs) == []                                 # (beyond 256 bytes: cut into fragments, step 4b)
+    monkeypatch.setenv("TK_FLAT_CUT", "0")                                    # without the cuts those documents are handed back
     flagged = _emu_check(test_vocab, docs)
     assert set(flagged) == set(range(len(kept), len(docs))), flagged
     for bos, eos in ((False, False), (True, False)):
         _emu_check(test_vocab, docs, bos, eos)
+
+
+def test_emu_cut_decomposition(test_vocab):
+    """Step 4b of the flat kernel (CUT instantiation; model tools/cut_model.py): a piece of more than 64 bytes is cut wherever no
+    vocabulary token can span the boundary, its fragments merge independently (no whole-piece look-up for a fragment) and its
+    document stays on the flat path -- letter runs of 65 bytes .. 6 KB that begin, end and continue at every kind of offset
+    around the chunk boundaries, several per stream, on the trained vocabulary (cuts everywhere) and on adversarial ones
+    (few cuts: fragments of more than 64 bytes become records, open fragments hand their document back)."""
+    import random
+    import gen_golden_merge as gg
+    rng = random.Random(5)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    filler = b"ab cd ef gh ij kl mn op qr st uv wx yz " * 120
+    docs = []
+    for n in (65, 96, 97, 200, 256, 257, 300, 1000, 1888, 1952, 2000, 2048, 4000, 6000):
+        w = "".join(rng.choice(letters) for _ in range(n)).encode()
+        docs += [w, b"x " + w + b" y", filler[:1899] + w + b" " + filler[:300]]
+    for k in range(1850, 2080, 9):                                            # the run's first byte / last byte walks over a chunk boundary
+        w = "".join(rng.choice(letters) for _ in range(400)).encode()
+        docs.append(filler[:k] + b" " + w + b" " + filler[:100])
+        docs.append(w[:k % 400 + 70] + b" " + filler[:50])
+    assert _emu_check(test_vocab, docs) == []
+    for bos, eos in ((False, False), (True, False)):
+        _emu_check(test_vocab, docs[:12], bos, eos)
+    n_docs = n_flagged = 0
+    for alphabet, n_extra, max_len in (("ab", 60, 6), ("abc", 250, 5), ("abcdefgh", 300, 5), ("aé中", 90, 4), ("abcdefghijklmnop", 200, 4), ("ab \n", 40, 5)):
+        toks = gg.vocab_adversarial(rng, alphabet, n_extra, max_len)
+        v = {"tokens": toks, "num_special": 5, "bos": 1, "eos": 2}
+        docs = []
+        for n in (64, 65, 66, 95, 96, 97, 130, 257, 700, 1900, 1952, 2048, 4100):
+            w = "".join(rng.choice(alphabet) for _ in range(n)).encode()
+            docs.append(filler[:rng.randint(0, 2100)] + w + b" " + filler[:rng.randint(0, 300)])
+            docs.append(w)
+        n_flagged += len(_emu_check(v, docs, check_split=False))
+        n_docs += len(docs)
+    assert n_flagged < n_docs // 2
 
 
 def test_emu_long_records_on_adversarial_vocabularies():
@@ -139,7 +177,8 @@ def test_emu_long_records_on_adversarial_vocabularies():
 
 
 def test_emu_flat_handback_and_mixed(test_vocab):
-    docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120)
+    # (a white-space run that crosses a region end is always handed back; long letter runs no longer are: step 4b)
+    docs = helpers.mixed_docs(8, 8, 8, max_len=3000) + helpers.random_unicode_docs(120) + [b"a b" + b" " * 3000 + b"x", b"1" * 2500]
     flagged = _emu_check(test_vocab, docs)
     assert flagged and len(flagged) < len(docs)           # both routes were taken inside one stream
     # empty documents in every position, a single document, only empty documents

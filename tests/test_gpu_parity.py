@@ -105,7 +105,8 @@ def test_both_pipelines(tk, test_vocab, monkeypatch):
     """The flat chunk-per-wave pipeline (default) and the per-document pipeline (TK_PIPELINE=doc) give the same ids;
     the flat one hands documents with very long runs / pieces back and says how many."""
     orc = helpers.oracle_for(test_vocab)
-    docs = helpers.mixed_docs(120, 40, 200, max_len=40000) + helpers.random_unicode_docs(300)
+    # (a white-space run across a region end and a long digit run are always handed back; long letter runs are cut: step 4b)
+    docs = helpers.mixed_docs(120, 40, 200, max_len=40000) + helpers.random_unicode_docs(300) + [b"a b" + b" " * 3000 + b"x", b"1" * 2500]
     exp = [orc.encode(d, True, True) for d in docs]
     monkeypatch.setenv("TK_PIPELINE", "flat")
     flat = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
@@ -661,7 +662,7 @@ def test_sparse_miss_queues(tk, eng_bench, bench_vocab):
 
 def test_long_pieces_stay_on_the_flat_path(tk, eng_small, eng_bench, test_vocab, bench_vocab, monkeypatch):
     """Pieces of 65..256 bytes (csrc/tk_flat_impl.h step 6, tk_flat_long_kernel): their documents are not handed back; beyond 256
-    bytes they are.  Letter runs, CJK paragraphs, rulers, the first byte of the piece walking over a chunk boundary, many
+    bytes they are unless the piece can be cut (step 4b; TK_FLAT_CUT=0 shows the hand-back).  Letter runs, CJK paragraphs, rulers, the first byte of the piece walking over a chunk boundary, many
     such pieces per document; the same batch with the path switched off (TK_FLAT_LONG=0) gives the same ids."""
     import random
     rng = random.Random(5)
@@ -692,9 +693,17 @@ def test_long_pieces_stay_on_the_flat_path(tk, eng_small, eng_bench, test_vocab,
     for eng, v in ((eng_small, test_vocab), (eng_bench, bench_vocab)):
         orc = helpers.oracle_for(v)
         ids, oo = check_batch(eng, orc, data, offs)
-        assert eng.last_stats()["handed_back"] == len(handed)
-        assert eng.long_piece_records() > 2000          # (the CJK paragraphs alone hold a few thousand such pieces)
+        # (the random-letter pieces beyond 256 bytes are cut into fragments -- step 4b -- and stay as well)
+        # (so are the CJK runs on these synthetic vocabularies -- their ideographs are random, no token spans two of them --;
+        # the records proper are exercised by the TK_FLAT_CUT=0 engine below: a few thousand pieces)
+        assert eng.last_stats()["handed_back"] == 0 and eng.cut_chunks() > 0
         check_batch(eng, orc, data, offs, False, False)
+    monkeypatch.setenv("TK_FLAT_CUT", "0")              # without the cuts: beyond 256 bytes the document is handed back
+    e1 = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
+    ids1, oo1 = e1.encode_batch(data, offs, True, True)
+    assert e1.last_stats()["handed_back"] == len(handed) and e1.cut_chunks() == 0 and e1.long_piece_records() > 2000
+    assert np.array_equal(ids1, ids) and np.array_equal(oo1, oo)
+    e1.close()
     monkeypatch.setenv("TK_FLAT_LONG", "0")
     e0 = tk.Engine(bench_vocab["tokens"], bench_vocab["num_special"], bench_vocab["bos"], bench_vocab["eos"], device=0)
     ids0, oo0 = e0.encode_batch(data, offs, True, True)
@@ -809,6 +818,7 @@ def test_long_pieces_merged_in_rounds(tk, test_vocab, bench_vocab, monkeypatch):
     for v in (test_vocab, bench_vocab):
         orc = helpers.oracle_for(v)
         exp = [orc.encode(d, True, True) for d in docs]
+        monkeypatch.setenv("TK_FLAT_CUT", "0")   # (with the cut decomposition the random-letter pieces never get here)
         # (lm, force): force = every long piece takes the rounds; without it only the repetitive ones do (the shipped policy:
         # on a piece with many distinct pairs a round costs more than the handful of merges it makes)
         # force 1 = every long piece through the compacting rounds, 2 = through the lazy rounds, 0 = routed by pair diversity

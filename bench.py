@@ -299,7 +299,7 @@ def main():
                               "pipeline_ms": round(float(np.mean(pipe_ms)), 4),
                               "pipeline_frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, **traffic_info),
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
-            "handed_back_docs": eng.last_stats()["handed_back"], "long_piece_records": eng.long_piece_records(), "cut_chunks": eng.cut_chunks(),
+            "handed_back_docs": eng.last_stats()["handed_back"], "long_piece_records": eng.long_piece_records(), "cut_chunks": eng.cut_chunks(), "host_syncs": eng.last_host_syncs(),
             "node": {"MBps_gather_inclusive": round(value, 1), "MBps_kernels_only": None if kernel_only is None else round(kernel_only, 1),
                      "per_gpu_kernel_ms": [round(t, 4) for t in k_times], "per_gpu_kernel_ms_max_over_mean": round(max(k_times) / (sum(k_times) / len(k_times)), 4) if sum(k_times) > 0 else None,
                      "per_gpu_input_bytes": [int(p[1]) for p in per_rank]},

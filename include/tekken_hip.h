@@ -101,6 +101,10 @@ uint64_t tk_long_piece_records(const tk_ctx* ctx);
  * flat kernel (csrc/tk_flat_impl.h step 4b: such a piece is cut into fragments wherever no vocabulary token can span the
  * boundary, and the fragments merge independently -- exact; diagnostics / tests; TK_FLAT_CUT=0 switches the cuts off). */
 uint64_t tk_cut_chunks(const tk_ctx* ctx);
+/* Host waits of the LAST batch on the flat pipeline: 2 -- the list of the documents the flat kernel handed back (made on a
+ * second stream beside the merge kernels), then the result; 3 only when a long-piece record flagged a document late
+ * (diagnostics / tests; TK_TAIL=serial at context creation runs the tail behind the merge kernels on the one stream). */
+uint64_t tk_last_host_syncs(const tk_ctx* ctx);
 
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference

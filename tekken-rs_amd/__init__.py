@@ -112,6 +112,9 @@ def lib():
     L.tk_round_path_docs.argtypes = [vp]
     L.tk_long_piece_records.restype = ctypes.c_uint64
     L.tk_long_piece_records.argtypes = [vp]
+    if hasattr(L, "tk_last_host_syncs"):
+        L.tk_last_host_syncs.restype = ctypes.c_uint64
+        L.tk_last_host_syncs.argtypes = [vp]
     if hasattr(L, "tk_cut_chunks"):   # (diagnostics only; tools/ab_bench.sh also loads libraries built before it existed)
         L.tk_cut_chunks.restype = ctypes.c_uint64
         L.tk_cut_chunks.argtypes = [vp]
@@ -337,6 +340,10 @@ class Engine:
     def cut_chunks(self):
         """Regions of the last batch whose long pieces were cut into independently merged fragments."""
         return int(lib().tk_cut_chunks(self._h)) if hasattr(lib(), "tk_cut_chunks") else 0
+
+    def last_host_syncs(self):
+        """Host waits of the last batch on the flat pipeline."""
+        return int(lib().tk_last_host_syncs(self._h)) if hasattr(lib(), "tk_last_host_syncs") else 0
 
     def small_path_calls(self):
         """Calls served by the one-launch small-batch path so far."""

@@ -139,6 +139,13 @@ struct tk_ctx {
     bool no_flat_long128 = false;  // TK_FLAT_LONG128=0: every long-piece record takes the single-wave merge
     bool no_flat_long = false;     // TK_FLAT_LONG=0: such pieces hand their documents back (the round-1 behaviour; A / B and tests)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the tail of a batch (documents handed back by the flat kernel) runs on a second stream beside the merge kernels
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};   // flat kernel done (A) | list of handed-back documents on the host (B) | tail done (B)
+    DevBuf scratch_rec;            // scratch of the long-piece record kernels (stream A; c->scratch belongs to the tail on stream B)
+    DevBuf f_late;                 // documents a long-piece record flagged after the list of handed-back documents was made
+    bool serial_tail = false;      // TK_TAIL=serial: the tail behind the merge kernels on the one stream (A / B, tests)
+    uint32_t host_syncs = 0;       // host waits of the last flat-pipeline call (diagnostics)
     float pipeline_ms = 0.f, encode_ms = 0.f;
     uint64_t n_long_docs = 0;
     uint32_t* dbg_mark = nullptr;  // pinned host memory, only with TK_DEBUG_MARKS
@@ -213,6 +220,10 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     }
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
+    if (hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TK_ERR_RUNTIME); }
+    for (int i = 0; i < 3; ++i)
+        if (hipEventCreateWithFlags(&c->ev_b[i], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
+    if (const char* tl = getenv("TK_TAIL")) c->serial_tail = strcmp(tl, "serial") == 0;
     if (hipHostMalloc((void**)&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(TK_ERR_RUNTIME); }
 
     const TkHostTables& h = c->host;
@@ -288,6 +299,11 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 3; ++i)
+        if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
+    c->scratch_rec.release();
+    c->f_late.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     DevBuf* pbufs[] = {&c->in_bytes2, &c->in_offs2, &c->out_ids2, &c->out_offs2};
@@ -395,8 +411,72 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
     return TK_OK;
 }
 
+// The same passes WITHOUT a host sync, for the flat pipeline's tail: the documents are a.todo_list = `list`, their number lives
+// in device memory (count_dev; NULL: n_bound is exact), n_bound and maxlen bound it and every document's length from above.
+// Pass 2, then -- always, the long list's length never leaves the device either -- walk, round-based merges, compaction
+// (tk_long.hip); with an empty long list those three kernels find nothing to do.
+static int enqueue_pass2(tk_ctx* c, TkEncodeArgs a, const uint32_t* list, const uint32_t* count_dev, uint32_t n_bound,
+                         uint64_t maxlen, uint64_t n_bytes, hipStream_t s, uint64_t max_waves = 1024) {
+    const uint64_t words = ((5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;
+    const uint64_t budget_words = (8ull << 30) / 4;
+    const uint64_t fit = budget_words / words >= 4 ? budget_words / words : 4;   // scratch slices the budget allows
+    uint64_t waves2 = n_bound < max_waves ? n_bound : max_waves;
+    if (waves2 > fit) waves2 = fit;
+    waves2 = ((waves2 + 3) / 4) * 4;
+    if (waves2 == 0) waves2 = 4;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    uint64_t walk_waves = ((n_bound < 1024u ? n_bound : 1024u) + 3) / 4 * 4;
+    uint64_t blocks = (uint64_t)cus;                                       // one 16-wave block per CU (158 KB of LDS)
+    if (walk_waves > fit) walk_waves = fit / 4 * 4;
+    if (blocks > fit) blocks = fit;
+    uint64_t slices = waves2;
+    if (c->long_min) slices = std::max(slices, std::max(walk_waves, blocks));
+    TK_HIP(c, c->scratch.reserve(slices * words * 4));
+    a.todo_list = list;
+    a.n_todo = n_bound;
+    a.n_todo_dev = count_dev;
+    a.defer_count = (uint32_t*)c->counters.p + 5;                          // (pass 2 defers nothing; count_dev may be counter 1)
+    a.scratch = (uint32_t*)c->scratch.p;
+    a.scratch_words_per_wave = words;
+    uint32_t* d_long_count = (uint32_t*)c->counters.p + 9;
+    if (c->long_min) {
+        TK_HIP(c, c->long_list.reserve(((size_t)n_bound + 1) * 4));
+        a.long_list = (uint32_t*)c->long_list.p;
+        a.long_count = d_long_count;
+        a.long_min = c->long_min < 65u ? 65u : c->long_min;
+        a.long_lazy_mul = c->long_lazy_mul;
+        a.long_force = c->long_force;
+    }
+    TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
+    TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 9, 0, 8, s));     // long list length, job count
+    TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
+    if (c->long_min) {
+        // a job is a piece of at least long_min bytes: no more of them than the text holds, nor than every document's share
+        uint64_t job_cap = maxlen / a.long_min * (uint64_t)n_bound + n_bound + 16;
+        if (job_cap > n_bytes / a.long_min + n_bound + 16) job_cap = n_bytes / a.long_min + n_bound + 16;
+        TK_HIP(c, c->long_jobs.reserve(job_cap * sizeof(TkLongJob)));
+        TkEncodeArgs b = a;
+        b.todo_list = (const uint32_t*)c->long_list.p;
+        b.n_todo = n_bound;
+        b.n_todo_dev = d_long_count;
+        b.long_list = nullptr;
+        b.long_jobs = (TkLongJob*)c->long_jobs.p;
+        b.long_job_count = (uint32_t*)c->counters.p + 10;
+        b.long_job_cap = (uint32_t)(job_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : job_cap);
+        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
+        TK_HIP(c, tk_launch_encode_long(b, (uint32_t)walk_waves, 0, s));
+        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counter
+        const uint64_t cblocks = ((uint64_t)n_bound + 3) / 4 < 4096 ? ((uint64_t)n_bound + 3) / 4 : 4096;
+        TK_HIP(c, tk_launch_encode_long_merge(b, (uint32_t)blocks, (uint32_t)cblocks, s));
+    }
+    return TK_OK;
+}
+
 // counters layout (u32): [0] work queue head, [1] deferred documents, [2] invalid docs, [3] max deferred length,
-// [4] documents the flat path handed back
+// [4] documents the flat path handed back (counted by the counts kernel), [5] scratch, [6..7] total ids, [9] long list, [10] long
+// jobs, [11] long-piece records, [12] cut chunks, [13] handed-back documents as listed (tk_flat_todo_kernel), [14] the longest of
+// them, [15] documents flagged late by a long-piece record; [16..20] control words of the flat kernel
 static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
                         int add_bos, int add_eos, hipStream_t s, uint64_t* n_ids) {
     const uint64_t cap = n_bytes + 2 * n_docs + 64;
@@ -566,60 +646,71 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         *n_ids = 0;
         return TK_OK;
     }
+    // The list of the handed-back documents is made on a second stream (B) right behind the flat kernel, beside the merge
+    // kernels, and comes to the host first: if there are such documents, the per-document passes over them run on B while
+    // stream A is still merging -- the tail of a batch (Zipf shape: pass 2, walk, round-based merges, compaction; each as long
+    // as its longest document) is hidden instead of appended.  Two host waits per call: the list, the result.
+    uint32_t* ctr = (uint32_t*)c->counters.p;
+    const bool serial = c->serial_tail;
+    hipStream_t sb = serial ? s : c->stream_b;
+    c->host_syncs = 0;
+    if (!serial) {
+        TK_HIP(c, hipEventRecord(c->ev_b[0], s));
+        TK_HIP(c, hipStreamWaitEvent(sb, c->ev_b[0], 0));
+    }
+    TK_HIP(c, tk_launch_flat_todo(fa.flags, d_offs, n_docs, (uint32_t*)c->f_todo.p, ctr + 13, ctr + 14, sb));
+    if (!serial) {
+        TK_HIP(c, hipMemcpyAsync(c->h_pin + 32, ctr, 64, hipMemcpyDeviceToHost, sb));
+        TK_HIP(c, hipEventRecord(c->ev_b[1], sb));
+    }
     TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_merge(fa, s));
     uint64_t total = 0;
-    uint32_t n_todo = 0, n_lrec = 0;
-    auto finish = [&](int final_pass) -> int {
+    auto finish = [&](int final_pass, bool wait) -> int {
         TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, d_P, fa.lstart, fa.flags, fa.holes, extra,
-                                        (uint32_t*)c->counts.p, c->f_info.p, final_pass, (uint32_t*)c->counters.p + 4, s));
+                                        (uint32_t*)c->counts.p, c->f_info.p, final_pass, ctr + 4, s));
         TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
                                           (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id,
-                                          c->host.eos_id, add_bos, add_eos, (uint64_t*)((uint32_t*)c->counters.p + 6),
-                                          final_pass ? nullptr : (const uint32_t*)c->counters.p + 4, s));
+                                          c->host.eos_id, add_bos, add_eos, (uint64_t*)(ctr + 6),
+                                          final_pass ? nullptr : (const uint32_t*)ctr + 4, s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
-        // counters 4 (handed-back documents), 6..7 (total ids, left there by the assembly) and 11 (long-piece records): one
-        // copy into pinned memory
-        TK_HIP(c, hipMemcpyAsync(c->h_pin, c->counters.p, 52, hipMemcpyDeviceToHost, s));
-        TK_HIP(c, hipStreamSynchronize(s));
-        memcpy(&total, c->h_pin + 6, 8);
-        if (!final_pass) { n_todo = c->h_pin[4]; n_lrec = c->h_pin[11]; c->n_cut_chunks = c->h_pin[12]; }
+        // every counter of the batch with one copy into pinned memory (6..7: the total, left there by the assembly)
+        TK_HIP(c, hipMemcpyAsync(c->h_pin, ctr, 64, hipMemcpyDeviceToHost, s));
+        if (wait) {
+            TK_HIP(c, hipStreamSynchronize(s));
+            ++c->host_syncs;
+            memcpy(&total, c->h_pin + 6, 8);
+        }
         return TK_OK;
     };
-    int rc = finish(0);
+    // optimistic: if nothing was handed back and no long-piece record waits, this IS the result (the assembly copies nothing otherwise)
+    int rc = finish(0, serial);
     if (rc != TK_OK) return rc;
+    const uint32_t* early = c->h_pin;
+    if (!serial) {
+        TK_HIP(c, hipEventSynchronize(c->ev_b[1]));
+        ++c->host_syncs;
+        early = c->h_pin + 32;
+    }
+    const uint32_t n_todo = early[13];
+    uint32_t n_lrec = early[11];
+    const uint64_t maxlen = early[14];
+    c->n_cut_chunks = early[12];
     c->n_flagged = n_todo;
     c->n_long_docs = 0;
-    if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u\n", (unsigned long long)n_docs,
-                     (unsigned long long)n_chunks, n_todo);
-    if (n_lrec) {
-        // the long-piece records: one wave each (lookup / single-wave merge into the reserved slots); a piece that turns out
-        // longer than TKF_LONGCAP flags its document, so the handed-back documents are counted again afterwards
-        if (n_lrec > fa.long_cap) n_lrec = fa.long_cap;
-        c->n_long_recs = n_lrec;
-        fa.long_merge128 = c->no_flat_long128 ? 0 : 1;
-        const uint32_t lwaves = ((n_lrec < 8192u ? n_lrec : 8192u) + 3u) / 4u * 4u;
-        TK_HIP(c, c->scratch.reserve((size_t)lwaves * TKF_LONG_SCRATCH_WORDS * 4));
-        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
-        TK_HIP(c, tk_launch_flat_long(fa, (uint32_t*)c->counters.p, (uint32_t*)c->scratch.p, TKF_LONG_SCRATCH_WORDS, lwaves, s));
+    c->n_long_recs = 0;
+    if (dbg) fprintf(stderr, "[tk] flat: docs=%llu chunks=%llu handed back=%u (longest %llu bytes) long-piece records=%u cut chunks=%u\n",
+                     (unsigned long long)n_docs, (unsigned long long)n_chunks, n_todo, (unsigned long long)maxlen, n_lrec, early[12]);
+    if (n_todo == 0 && n_lrec == 0) {
+        if (!serial) {
+            TK_HIP(c, hipStreamSynchronize(s));
+            ++c->host_syncs;
+            memcpy(&total, c->h_pin + 6, 8);
+        }
     } else {
-        c->n_long_recs = 0;
-    }
-    if (n_todo || n_lrec) {
         TK_HIP(c, c->staging.reserve((n_bytes + 2 * n_docs + 64) * 4));
         TK_HIP(c, c->defer_list.reserve((n_docs + 1) * 4));
-        TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 4, 0, 4, s));
-        TK_HIP(c, tk_launch_flat_todo(fa.flags, n_docs, (uint32_t*)c->f_todo.p, (uint32_t*)c->counters.p + 4, s));
-        if (n_lrec) {
-            TK_HIP(c, hipMemcpyAsync(c->h_pin + 4, (uint32_t*)c->counters.p + 4, 4, hipMemcpyDeviceToHost, s));
-            TK_HIP(c, hipStreamSynchronize(s));
-            n_todo = c->h_pin[4];
-            c->n_flagged = n_todo;
-        }
-    }
-    if (n_todo) {
-        // the per-document path over the handed-back documents: pass 1 (mode 3), then pass 2 for its own deferrals
         TkEncodeArgs a;
         memset(&a, 0, sizeof(a));
         a.bytes = d_bytes;
@@ -627,40 +718,81 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         a.n_docs = n_docs;
         a.staging = (uint32_t*)c->staging.p;
         a.counts = (uint32_t*)c->counts.p;
-        a.work_counter = (uint32_t*)c->counters.p;
-        a.defer_count = (uint32_t*)c->counters.p + 1;
+        a.work_counter = ctr;
+        a.defer_count = ctr + 1;
         a.defer_list = (uint32_t*)c->defer_list.p;
-        a.todo_list = (const uint32_t*)c->f_todo.p;
-        a.n_todo = n_todo;
         a.add_bos = add_bos;
         a.add_eos = add_eos;
         a.t = c->dview;
         a.pattern = c->pattern;
-        if (c->pattern == 1) {
-            // JSON pattern: the handed-back documents go straight to the piece-by-piece path with its sequential matcher
-            c->n_long_docs = n_todo;
-            TK_HIP(c, hipMemcpyAsync(c->defer_list.p, c->f_todo.p, (size_t)n_todo * 4, hipMemcpyDeviceToDevice, s));   // pass 2 reads defer_list
-            int rc2 = run_pass2(c, a, d_offs, n_todo, s, 8192);
-            if (rc2 != TK_OK) return rc2;
-        } else {
-            TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 8, s));
-            const uint64_t want = ((uint64_t)n_todo + 7) / 8;
-            TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), s));
-            uint32_t n_def = 0;
-            TK_HIP(c, hipMemcpyAsync(&n_def, (uint32_t*)c->counters.p + 1, 4, hipMemcpyDeviceToHost, s));
-            TK_HIP(c, hipStreamSynchronize(s));
-            c->n_long_docs = n_def;
-            if (n_def) {
-                int rc2 = run_pass2(c, a, d_offs, n_def, s);
+        if (n_lrec) {
+            // stream A: the long-piece records, one wave each (lookup / merge into the reserved slots); a piece that turns out
+            // longer than TKF_LONGCAP flags its document and puts it on the late list (counter 15)
+            if (n_lrec > fa.long_cap) n_lrec = fa.long_cap;
+            c->n_long_recs = n_lrec;
+            fa.long_merge128 = c->no_flat_long128 ? 0 : 1;
+            const uint32_t lwaves = ((n_lrec < 8192u ? n_lrec : 8192u) + 3u) / 4u * 4u;
+            TK_HIP(c, c->scratch_rec.reserve((size_t)lwaves * TKF_LONG_SCRATCH_WORDS * 4));
+            TK_HIP(c, c->f_late.reserve((n_docs + 1) * 4));
+            fa.late_list = (uint32_t*)c->f_late.p;
+            fa.late_count = ctr + 15;
+            TK_HIP(c, tk_launch_flat_long(fa, ctr, (uint32_t*)c->scratch_rec.p, TKF_LONG_SCRATCH_WORDS, lwaves, s));
+        }
+        if (n_todo) {
+            // stream B: the per-document path over the handed-back documents -- pass 1 (mode 3), then, for what it defers (the
+            // count stays on the device), pass 2 and the round-based kernels
+            a.todo_list = (const uint32_t*)c->f_todo.p;
+            a.n_todo = n_todo;
+            if (c->pattern == 1) {
+                // JSON pattern: the handed-back documents go straight to the piece-by-piece path with its sequential matcher
+                int rc2 = enqueue_pass2(c, a, (const uint32_t*)c->f_todo.p, nullptr, n_todo, maxlen, n_bytes, sb, 8192);
+                if (rc2 != TK_OK) return rc2;
+            } else {
+                TK_HIP(c, hipMemsetAsync(ctr, 0, 8, sb));
+                const uint64_t want = ((uint64_t)n_todo + 7) / 8;
+                TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), sb));
+                int rc2 = enqueue_pass2(c, a, (const uint32_t*)c->defer_list.p, ctr + 1, n_todo, maxlen, n_bytes, sb);
                 if (rc2 != TK_OK) return rc2;
             }
+            if (!serial) {
+                TK_HIP(c, hipEventRecord(c->ev_b[2], sb));
+                TK_HIP(c, hipStreamWaitEvent(s, c->ev_b[2], 0));
+            }
         }
-    }
-    if (n_todo || n_lrec) {
-        // (the long kernel has zeroed nothing the final pass reads: counter 11 still holds the record count, and the final
-        // assembly does not look at it)
-        rc = finish(1);
+        rc = finish(1, true);
         if (rc != TK_OK) return rc;
+        c->n_long_docs = c->pattern == 1 ? n_todo : c->h_pin[1];
+        c->n_round_docs += n_todo ? c->h_pin[9] : 0;
+        const uint32_t n_late = n_lrec ? c->h_pin[15] : 0;
+        if (n_late) {
+            // rare: documents that a long-piece record flagged (an open piece of more than TKF_LONGCAP bytes without a cut) after
+            // the list was made -- the same passes over the late list, in sequence, and the result is assembled again
+            c->n_flagged += n_late;
+            a.todo_list = (const uint32_t*)c->f_late.p;
+            a.n_todo = n_late;
+            a.n_todo_dev = nullptr;
+            a.defer_count = ctr + 1;
+            if (c->pattern == 1) {
+                TK_HIP(c, hipMemcpyAsync(c->defer_list.p, c->f_late.p, (size_t)n_late * 4, hipMemcpyDeviceToDevice, s));
+                int rc2 = run_pass2(c, a, d_offs, n_late, s, 8192);
+                if (rc2 != TK_OK) return rc2;
+                c->n_long_docs += n_late;
+            } else {
+                TK_HIP(c, hipMemsetAsync(ctr, 0, 8, s));
+                const uint64_t want = ((uint64_t)n_late + 7) / 8;
+                TK_HIP(c, tk_launch_encode(a, 3, (uint32_t)(want < 8192 ? want : 8192), s));
+                uint32_t n_def = 0;
+                TK_HIP(c, hipMemcpyAsync(&n_def, ctr + 1, 4, hipMemcpyDeviceToHost, s));
+                TK_HIP(c, hipStreamSynchronize(s));
+                c->n_long_docs += n_def;
+                if (n_def) {
+                    int rc2 = run_pass2(c, a, d_offs, n_def, s);
+                    if (rc2 != TK_OK) return rc2;
+                }
+            }
+            rc = finish(1, true);
+            if (rc != TK_OK) return rc;
+        }
     }
     (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[3], c->ev[2]);
@@ -1123,6 +1255,7 @@ extern "C" uint64_t tk_small_path_calls(const tk_ctx* c) { return c ? c->n_small
 extern "C" uint64_t tk_round_path_docs(const tk_ctx* c) { return c ? c->n_round_docs : 0; }
 extern "C" uint64_t tk_long_piece_records(const tk_ctx* c) { return c ? c->n_long_recs : 0; }
 extern "C" uint64_t tk_cut_chunks(const tk_ctx* c) { return c ? c->n_cut_chunks : 0; }
+extern "C" uint64_t tk_last_host_syncs(const tk_ctx* c) { return c ? c->host_syncs : 0; }
 
 extern "C" int tk_last_stats(const tk_ctx* c, uint64_t* n_long_docs, uint64_t* reserved) {
     if (!c) return TK_ERR_INVALID_ARG;

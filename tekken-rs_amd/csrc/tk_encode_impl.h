@@ -1234,7 +1234,7 @@ template <int MODE>
 TK_DEV void tk_encode_wave(const TkEncodeArgs& a, int lane, uint64_t wave_id) {
     const TkPolyPow pw = tk_poly_pow(a.t, lane);
     uint32_t* scratch = MODE == 1 ? a.scratch + wave_id * a.scratch_words_per_wave : nullptr;
-    const uint64_t total = (MODE == 1 || MODE == 3) ? (uint64_t)a.n_todo : a.n_docs;
+    const uint64_t total = (MODE == 1 || MODE == 3) ? (uint64_t)(a.n_todo_dev ? wv_first(*a.n_todo_dev) : a.n_todo) : a.n_docs;
     const uint32_t chunk = MODE == 1 ? 1u : TK_DOC_CHUNK;
     for (;;) {
         // Every lane takes part in the fetch (the compiler folds it into ONE atomic of 64*chunk and

@@ -19,6 +19,7 @@ struct TkEncodeArgs {
     uint32_t* defer_count;
     const uint32_t* todo_list;  // pass 2: the documents to process
     uint32_t n_todo;
+    const uint32_t* n_todo_dev; // not NULL: the length of todo_list is read from here (a count that never left the device) instead of n_todo
     uint8_t* dbg_starts;        // optional: per-byte piece-start flags (tk_split_batch)
     volatile uint32_t* dbg_mark; // optional: progress marks of the long-piece merge (debug builds of the host)
     uint32_t* long_list;        // pass 2: documents with a long piece that misses the vocabulary, handed on to tk_long.hip (NULL: merged here)

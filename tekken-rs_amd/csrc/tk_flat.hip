@@ -191,8 +191,10 @@ __global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArg
     }
 }
 
-__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, uint64_t n_docs,
-                                                                  uint32_t* __restrict__ todo, uint32_t* __restrict__ n_todo) {
+// flagged documents -> list; the longest of them (it sizes the scratch of the piece-by-piece pass) -> *maxlen
+__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t* __restrict__ flags, const uint64_t* __restrict__ doc_offs,
+                                                                  uint64_t n_docs, uint32_t* __restrict__ todo,
+                                                                  uint32_t* __restrict__ n_todo, uint32_t* __restrict__ maxlen) {
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
     const bool f = d < n_docs && flags[d] != 0u;
     const uint64_t m = __ballot(f);
@@ -201,7 +203,11 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_todo_kernel(const uint32_t*
     uint32_t base = 0;
     if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(n_todo, (uint32_t)__builtin_popcountll(m));
     base = __shfl(base, (int)__builtin_ctzll(m));
-    if (f) todo[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)d;
+    if (f) {
+        todo[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)d;
+        const uint64_t len = doc_offs[d + 1] - doc_offs[d];
+        atomicMax(maxlen, (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len));
+    }
 }
 
 // ids of the stream before byte doc_offs[i]
@@ -243,11 +249,16 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_counts_kernel(const uint64_
     TkFlatDocInfo di;
     if (flagged) {
         if (final_pass) {  // the document keeps the count of the per-document kernel, the assembly copies it from staging
+            // (a document that a long-piece record flagged late has not been through those kernels yet and holds a stale count: no
+            // document has more ids than bytes + 2, which keeps this pass inside the buffers; the host then redoes it)
+            const uint64_t most = doc_offs[d + 1] - doc_offs[d] + 2;
+            if ((uint64_t)counts[d] > most) counts[d] = (uint32_t)most;
             di.src = doc_offs[d] + 2 * d;
             di.n_slots = counts[d];
             di.n_first = 0xFFFFFFFFu;
         } else {
-            counts[d] = extra;
+            // (counts[d] is left alone: the per-document kernels may be writing it right now, on the second stream -- whatever
+            // this pass computes for a batch with flagged documents is thrown away)
             di.src = 0; di.n_slots = 0; di.n_first = 0;
         }
         info[d] = di;
@@ -556,9 +567,10 @@ hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint
     return hipGetLastError();
 }
 
-hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s) {
+hipError_t tk_launch_flat_todo(const uint32_t* flags, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo,
+                               uint32_t* maxlen, hipStream_t s) {
     if (n_docs == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_flat_todo_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, flags, n_docs, todo, n_todo);
+    hipLaunchKernelGGL(tk_flat_todo_kernel, dim3(tkf_blocks(n_docs)), dim3(TKF_BLOCK), 0, s, flags, doc_offs, n_docs, todo, n_todo, maxlen);
     return hipGetLastError();
 }
 

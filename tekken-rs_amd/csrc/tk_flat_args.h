@@ -77,6 +77,9 @@ struct TkFlatArgs {
     uint32_t* cut_list;          // [n_chunks] chunks with a piece of more than 64 bytes: left by tk_flat_kernel to the CUT instantiation
                                  // (tk_flat_cut_kernel), which cuts such pieces into fragments where no token can span (NULL: no cuts)
     const uint32_t* cut_count;   // entries of cut_list (device counter 12)
+    uint32_t* late_list;         // [n_docs] documents that a long-piece record flags (an open piece beyond TKF_LONGCAP) after the list of
+                                 // the handed-back documents was made; NULL: the flag alone (the list is made afterwards)
+    uint32_t* late_count;
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
     int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,

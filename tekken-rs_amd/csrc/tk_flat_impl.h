@@ -1045,7 +1045,7 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     if (wv_first(a.flags[d]) != 0u) return;                 // handed back anyway: its slots are never read
     TkEncodeArgs ea;
     ea.bytes = a.bytes; ea.doc_offs = a.doc_offs; ea.n_docs = a.n_docs; ea.staging = nullptr; ea.counts = nullptr;
-    ea.work_counter = nullptr; ea.defer_count = nullptr; ea.defer_list = nullptr; ea.todo_list = nullptr; ea.n_todo = 0;
+    ea.work_counter = nullptr; ea.defer_count = nullptr; ea.defer_list = nullptr; ea.todo_list = nullptr; ea.n_todo = 0; ea.n_todo_dev = nullptr;
     ea.scratch = scratch; ea.scratch_words_per_wave = 0; ea.add_bos = 0; ea.add_eos = 0; ea.split_only = 0; ea.pattern = 0; ea.dbg_ablate = 0;
     ea.dbg_starts = nullptr; ea.dbg_mark = nullptr; ea.long_list = nullptr; ea.long_count = nullptr; ea.long_min = 0; ea.long_lazy_mul = 0; ea.long_force = 0;
     ea.long_jobs = nullptr; ea.long_job_count = nullptr; ea.long_job_cap = 0; ea.t = a.t;
@@ -1056,7 +1056,15 @@ TK_DEV void tk_flat_long_wave(const TkFlatArgs& a, const TkPolyPow& pw, uint32_t
     const uint32_t len = (uint32_t)(e - g);
     uint32_t* out = a.tmp + (uint64_t)lr.chunk * TKF_STRIDE + lr.slot;
     if (e - g > (uint64_t)lr.reserved) {                    // an open piece of more than LONGCAP bytes: the per-document kernels take the document
-        if (lane == 0) a.flags[d] = 1u;
+        if (lane == 0) {
+            // (flagged AFTER the list of the handed-back documents was made -- it is made right behind the flat kernel, beside
+            // the merge kernels --: the first record to flag a document puts it on the late list)
+            if (a.late_list) {
+                if (wv_atomic_exch(a.flags + d, 1u) == 0u) a.late_list[wv_atomic_add(a.late_count, 1u)] = (uint32_t)d;
+            } else {
+                a.flags[d] = 1u;
+            }
+        }
         return;
     }
     uint32_t cur = 0;

@@ -46,7 +46,9 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s);
 #define TKF_LONG_SCRATCH_WORDS 2048u
 hipError_t tk_launch_flat_long(const TkFlatArgs& a, uint32_t* work_counter, uint32_t* scratch, uint32_t scratch_words, uint32_t n_waves,
                                hipStream_t s);
-hipError_t tk_launch_flat_todo(const uint32_t* flags, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo, hipStream_t s);
+// flagged documents -> todo list (count in *n_todo), the longest of them in *maxlen (atomicMax: zero it first)
+hipError_t tk_launch_flat_todo(const uint32_t* flags, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* todo, uint32_t* n_todo,
+                               uint32_t* maxlen, hipStream_t s);
 // doc_info: [n_docs] 16-byte records (TkFlatDocInfo, tk_flat.hip) written by counts, read by assemble
 hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint64_t n_chunks,
                                  const uint64_t* P, const uint32_t* lstart, const uint32_t* flags, const uint32_t* holes,

@@ -579,10 +579,11 @@ __global__ __launch_bounds__(256) void tk_long_walk_kernel(TkEncodeArgs a) {
     const TkPolyPow pw = tk_poly_pow(t, lane);
     const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     uint32_t* scratch = a.scratch + wave_id * a.scratch_words_per_wave;
+    const uint32_t n_todo = a.n_todo_dev ? wv_first(*a.n_todo_dev) : a.n_todo;
     for (;;) {
         const uint32_t ticket = wv_first(wv_atomic_add_all(a.work_counter, 1u));   // (all lanes take part: see tk_encode_wave)
         const uint32_t q = ticket / 64u;
-        if (q >= a.n_todo) break;
+        if (q >= n_todo) break;
         const uint64_t d = (uint64_t)wv_first(a.todo_list[q]);
         const uint64_t s0 = wv_first64(a.doc_offs[d]), s1 = wv_first64(a.doc_offs[d + 1]);
         uint32_t* out = a.staging + s0 + 2 * d;
@@ -649,7 +650,8 @@ __global__ __launch_bounds__(256) void tk_long_compact_kernel(TkEncodeArgs a) {
     const int lane = wv_lane();
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * 4;
-    for (uint64_t q = wave; q < a.n_todo; q += n_waves) {
+    const uint32_t n_todo = a.n_todo_dev ? *a.n_todo_dev : a.n_todo;
+    for (uint64_t q = wave; q < n_todo; q += n_waves) {
         const uint64_t d = a.todo_list[q];
         const uint64_t s0 = a.doc_offs[d], s1 = a.doc_offs[d + 1];
         uint32_t* out = a.staging + s0 + 2 * d + (a.add_bos ? 1u : 0u);
@@ -674,12 +676,12 @@ __global__ __launch_bounds__(256) void tk_long_compact_kernel(TkEncodeArgs a) {
 // the long list (documents pass 2 handed on): walk, merge the jobs, compact.  scratch: args.scratch_words_per_wave words
 // per walking wave / per merging workgroup.
 hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves, uint32_t n_merge_blocks, hipStream_t s) {
-    if (args.n_todo == 0) return hipSuccess;
+    if (args.n_todo == 0 && !args.n_todo_dev) return hipSuccess;
     hipLaunchKernelGGL(tk_long_walk_kernel, dim3((n_walk_waves + 3) / 4), dim3(256), 0, s, args);
     return hipGetLastError();
 }
 hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s) {
-    if (args.n_todo == 0) return hipSuccess;
+    if (args.n_todo == 0 && !args.n_todo_dev) return hipSuccess;
     hipLaunchKernelGGL(tk_long_merge_kernel, dim3(n_merge_blocks), dim3(TKL_THREADS), 0, s, args);
     hipLaunchKernelGGL(tk_long_compact_kernel, dim3(n_compact_blocks), dim3(256), 0, s, args);
     return hipGetLastError();

@@ -58,6 +58,7 @@ TK_DEV void wv_sync() {
 TK_DEV uint64_t wv_brev64(uint64_t x) { return __builtin_bitreverse64(x); }  // s_brev_b64 on uniform values
 
 TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+TK_DEV uint32_t wv_atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
 
 // executed by ALL 64 lanes in uniform control flow: *p += 64*v, lane i receives old + i*v
 TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -125,7 +125,7 @@ struct tk_ctx {
     DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
     DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
     uint32_t long_lazy_mul = 0;    // TK_LONG_LAZY_MUL (0 = the default of tk_piece_is_long)
-    uint32_t long_min = 1024;      // shortest piece (bytes) merged in rounds by a workgroup (TK_LONG_MIN; 0 = never)
+    uint32_t long_min = 256;       // shortest piece (bytes) merged in rounds by a workgroup (TK_LONG_MIN; 0 = never)
     uint32_t long_force = 0;       // TK_LONG_FORCE (tests): rounds for every long piece, not only the repetitive ones
     uint64_t n_round_docs = 0;     // documents the round-based kernel took in the last call
     DevBuf f_first, f_tmp, f_lstart, f_flags, f_todo, f_miss, f_mcnt, f_mpfx, f_wfirst, f_info;  // flat path (tk_flat.hip)
@@ -413,8 +413,8 @@ static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_
 
 // The same passes WITHOUT a host sync, for the flat pipeline's tail: the documents are a.todo_list = `list`, their number lives
 // in device memory (count_dev; NULL: n_bound is exact), n_bound and maxlen bound it and every document's length from above.
-// Pass 2, then -- always, the long list's length never leaves the device either -- walk, round-based merges, compaction
-// (tk_long.hip); with an empty long list those three kernels find nothing to do.
+// Walk (one wave per document, piece by piece; long pieces become jobs), round-based merges of the jobs, compaction
+// (tk_long.hip); TK_LONG_MIN=0: pass 2 alone.
 static int enqueue_pass2(tk_ctx* c, TkEncodeArgs a, const uint32_t* list, const uint32_t* count_dev, uint32_t n_bound,
                          uint64_t maxlen, uint64_t n_bytes, hipStream_t s, uint64_t max_waves = 1024) {
     const uint64_t words = ((5 * maxlen + 2 * ((maxlen + 63) / 64) + 64 + 3) / 4) * 4;
@@ -439,32 +439,28 @@ static int enqueue_pass2(tk_ctx* c, TkEncodeArgs a, const uint32_t* list, const 
     a.defer_count = (uint32_t*)c->counters.p + 5;                          // (pass 2 defers nothing; count_dev may be counter 1)
     a.scratch = (uint32_t*)c->scratch.p;
     a.scratch_words_per_wave = words;
-    uint32_t* d_long_count = (uint32_t*)c->counters.p + 9;
     if (c->long_min) {
-        TK_HIP(c, c->long_list.reserve(((size_t)n_bound + 1) * 4));
-        a.long_list = (uint32_t*)c->long_list.p;
-        a.long_count = d_long_count;
         a.long_min = c->long_min < 65u ? 65u : c->long_min;
         a.long_lazy_mul = c->long_lazy_mul;
         a.long_force = c->long_force;
     }
     TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
-    TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 9, 0, 8, s));     // long list length, job count
-    TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));
-    if (c->long_min) {
+    TK_HIP(c, hipMemsetAsync((uint32_t*)c->counters.p + 9, 0, 8, s));     // (9: unused on this path) job count
+    if (!c->long_min) {
+        TK_HIP(c, tk_launch_encode(a, 1, (uint32_t)waves2, s));             // (TK_LONG_MIN=0: no round-based merges -- pass 2 does it all)
+    } else {
         // a job is a piece of at least long_min bytes: no more of them than the text holds, nor than every document's share
         uint64_t job_cap = maxlen / a.long_min * (uint64_t)n_bound + n_bound + 16;
         if (job_cap > n_bytes / a.long_min + n_bound + 16) job_cap = n_bytes / a.long_min + n_bound + 16;
         TK_HIP(c, c->long_jobs.reserve(job_cap * sizeof(TkLongJob)));
+        // The walk takes EVERY document of the list (the first form ran pass 2 first and walked only the documents in which it
+        // met a long piece: two kernels in a row, each as long as its slowest document, the second redoing what the first
+        // had done of its documents)
         TkEncodeArgs b = a;
-        b.todo_list = (const uint32_t*)c->long_list.p;
-        b.n_todo = n_bound;
-        b.n_todo_dev = d_long_count;
         b.long_list = nullptr;
         b.long_jobs = (TkLongJob*)c->long_jobs.p;
         b.long_job_count = (uint32_t*)c->counters.p + 10;
         b.long_job_cap = (uint32_t)(job_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : job_cap);
-        TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));
         TK_HIP(c, tk_launch_encode_long(b, (uint32_t)walk_waves, 0, s));
         TK_HIP(c, hipMemsetAsync(c->counters.p, 0, 4, s));                   // the job queue's ticket counter
         const uint64_t cblocks = ((uint64_t)n_bound + 3) / 4 < 4096 ? ((uint64_t)n_bound + 3) / 4 : 4096;
@@ -762,7 +758,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         rc = finish(1, true);
         if (rc != TK_OK) return rc;
         c->n_long_docs = c->pattern == 1 ? n_todo : c->h_pin[1];
-        c->n_round_docs += n_todo ? c->h_pin[9] : 0;
+        c->n_round_docs += n_todo && c->long_min ? c->h_pin[10] : 0;   // (here: long pieces merged in rounds)
         const uint32_t n_late = n_lrec ? c->h_pin[15] : 0;
         if (n_late) {
             // rare: documents that a long-piece record flagged (an open piece of more than TKF_LONGCAP bytes without a cut) after

@@ -657,14 +657,22 @@ __global__ __launch_bounds__(256) void tk_long_compact_kernel(TkEncodeArgs a) {
         uint32_t* out = a.staging + s0 + 2 * d + (a.add_bos ? 1u : 0u);
         const uint32_t len = (uint32_t)(s1 - s0);
         uint32_t wr = 0;
-        for (uint32_t k0 = 0; k0 < len; k0 += 64u) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            const uint32_t v = k < len ? out[k] : TKL_HOLE;
-            const uint64_t keep = wv_ballot(v != TKL_HOLE);
-            // (the slots written are at or below the ones just read; the ballot orders the loads before the stores)
-            if (v != TKL_HOLE) out[wr + (uint32_t)tk_popc64(keep & tk_lowmask(lane))] = v;
-            wr += (uint32_t)tk_popc64(keep);
-            wv_sync();
+        // four groups of 64 slots per step, their loads issued together (a 32 KiB document is a chain of 128 such steps).  The
+        // slots written lie at or below the ones just read and the next step reads above them: no load ever meets a store of
+        // its own wave that it could overtake; the ballots order a step's loads before its stores.
+        for (uint32_t k0 = 0; k0 < len; k0 += 256u) {
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t k = k0 + 64u * (uint32_t)q + (uint32_t)lane;
+                v[q] = k < len ? out[k] : TKL_HOLE;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t keep = wv_ballot(v[q] != TKL_HOLE);
+                if (v[q] != TKL_HOLE) out[wr + (uint32_t)tk_popc64(keep & tk_lowmask(lane))] = v[q];
+                wr += (uint32_t)tk_popc64(keep);
+            }
         }
         if (lane == 0) {
             if (a.add_eos) out[wr] = a.t.eos_id;

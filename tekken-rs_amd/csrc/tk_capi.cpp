@@ -112,7 +112,8 @@ struct tk_ctx {
     TkHostTables host;
     TkTablesView dview;
     DevBuf t_uc1, t_uc2, t_key8, t_key, t_long, t_pair, t_pair2, t_pairf, t_blob, t_offs, t_spblob, t_spoffs, t_uc2a, t_uc2b;
-    DevBuf t_cutk2, t_cutg3;       // the cut rule's bit maps (tk_tables.cpp make_cut_tables)
+    DevBuf t_key64;                // whole pieces of 17..64 bytes by the flat kernel's dword hash
+    DevBuf t_cutk2, t_cutg3, t_ucbmp;   // the cut rule's bit maps, the class trie flattened for the BMP (tk_tables.cpp make_cut_tables)
     DevBuf f_cut;                  // flat path: chunks left to the CUT instantiation (tk_flat_cut_kernel)
     void* cut_ctl_ptr = nullptr;   // what the control words at counters + 19 describe
     bool no_flat_cut = false;      // TK_FLAT_CUT=0: no cut decomposition (pieces of more than 256 bytes hand their documents back; A / B and tests)
@@ -241,6 +242,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         (rc = upload(c, c->t_pair, h.pair_tab.data(), h.pair_tab.size() * 8)) ||
         (rc = upload(c, c->t_pair2, h.pair2.data(), h.pair2.size() * 4)) ||
         (rc = upload(c, c->t_pairf, h.pair_filter.data(), h.pair_filter.size() * 4)) ||
+        (rc = upload(c, c->t_ucbmp, h.uc_bmp.data(), h.uc_bmp.size() * 4)) ||
+        (rc = upload(c, c->t_key64, h.key64_tab.data(), h.key64_tab.size() * sizeof(tk_long_entry))) ||
         (rc = upload(c, c->t_cutk2, h.cut_k2.data(), h.cut_k2.size() * 4)) ||
         (rc = upload(c, c->t_cutg3, h.cut_g3.data(), h.cut_g3.size() * 4)) ||
         (rc = upload(c, c->t_blob, h.blob.data(), h.blob.size())) ||
@@ -257,6 +260,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     c->dview.pair_tab = (const uint64_t*)c->t_pair.p;
     c->dview.pair2 = (const uint32_t*)c->t_pair2.p;
     c->dview.pair_filter = (const uint32_t*)c->t_pairf.p;
+    c->dview.uc_bmp = (const uint32_t*)c->t_ucbmp.p;
+    c->dview.key64_tab = (const tk_long_entry*)c->t_key64.p;
     c->dview.cut_k2 = (const uint32_t*)c->t_cutk2.p;
     c->dview.cut_g3 = (const uint32_t*)c->t_cutg3.p;
     c->dview.blob = (const uint8_t*)c->t_blob.p;
@@ -290,7 +295,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
 extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->t_cutk2, &c->t_cutg3, &c->f_cut, &c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
+    DevBuf* bufs[] = {&c->t_key64, &c->t_ucbmp, &c->t_cutk2, &c->t_cutg3, &c->f_cut, &c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
                       &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->t_inline, &c->t_len8,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,

@@ -495,49 +495,75 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         wv_lds_sync();
         bool nmb = false;
         uint32_t w = m.LEAD;
+        // the char at byte i of this lane: its code point (0xFFFFFFFF: malformed) and byte length, from the LDS copy of the region
+        // (bytes outside [0, n) are zero there)
+        auto decode = [&](int i, uint32_t* clen_out) -> uint32_t {
+            const uint32_t p = (uint32_t)TKF_W * (uint32_t)lane + (uint32_t)i;
+            const uint32_t* tw = lds + TKF_L_TXT + (p >> 2);
+            const uint32_t v4 = wv_alignbyte(tw[1], tw[0], p & 3u);
+            const uint32_t b0 = v4 & 0xFFu, b1 = (v4 >> 8) & 0xFFu, b2 = (v4 >> 16) & 0xFFu, b3 = v4 >> 24;
+            uint32_t cp = 0xFFFFFFFFu, clen = 1;
+            if (b0 < 0xE0u) {
+                if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
+            } else if (b0 < 0xF0u) {
+                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
+                    cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
+                }
+            } else if (b0 < 0xF8u) {
+                if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
+                    cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
+                }
+            }
+            *clen_out = clen;
+            return cp;
+        };
+        auto mark = [&](int i, uint32_t clen, uint32_t cls, uint32_t extra) {
+            if (PAT && extra) {
+                const uint64_t xb = (uint64_t)((1u << clen) - 1u) << i;
+                wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane, (uint32_t)(xb & TKF_WM));
+                if ((xb >> TKF_W) && lane < 63) wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane + 1u, (uint32_t)(xb >> TKF_W));
+            }
+            if (cls != TK_CLS_O) {
+                const uint64_t bits = (uint64_t)((1u << clen) - 1u) << i;   // may reach into the next lane's word
+                wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
+                if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
+                if (cls == TK_CLS_N) nmb = true;
+            }
+        };
         while (wv_ballot(w != 0u)) {
             if (w) {
-                const int i = __builtin_ctz(w);
-                w &= w - 1u;
-                // the char's (up to) four bytes from the LDS copy of the region (bytes outside [0, n) are zero there)
-                const uint32_t p = (uint32_t)TKF_W * (uint32_t)lane + (uint32_t)i;
-                const uint32_t* tw = lds + TKF_L_TXT + (p >> 2);
-                const uint32_t v4 = wv_alignbyte(tw[1], tw[0], p & 3u);
-                const uint32_t b0 = v4 & 0xFFu, b1 = (v4 >> 8) & 0xFFu, b2 = (v4 >> 16) & 0xFFu, b3 = v4 >> 24;
-                uint32_t cp = 0xFFFFFFFFu, clen = 1;
-                if (b0 < 0xE0u) {
-                    if ((b1 & 0xC0u) == 0x80u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
-                } else if (b0 < 0xF0u) {
-                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
-                        cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
-                    }
-                } else if (b0 < 0xF8u) {
-                    if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
-                        cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
-                    }
-                }
-                uint32_t cls = TK_CLS_O;
-                uint32_t extra = 0;                      // JSON pattern: 1 upper case, 2 Lm | Lo, 3 mark -> a second mask word
-                if (cp != 0xFFFFFFFFu) {
-                    if (PAT) {
+                if (PAT) {
+                    const int i = __builtin_ctz(w);
+                    w &= w - 1u;
+                    uint32_t clen;
+                    const uint32_t cp = decode(i, &clen);
+                    uint32_t cls = TK_CLS_O, extra = 0;   // JSON pattern: 1 upper case, 2 Lm | Lo, 3 mark -> a second mask word
+                    if (cp != 0xFFFFFFFFu) {
                         // classes of unicode_tables2.h: 1 upper (Lu | Lt), 2 lower, 3 Lm | Lo, 4 mark, 5 N, 6 \s
                         const uint32_t c2 = tk_uc_class2(t, cp);
                         cls = c2 == 1u || c2 == 2u ? TK_CLS_L : c2 == 5u ? TK_CLS_N : c2 == 6u ? TK_CLS_S : TK_CLS_O;
                         extra = c2 == 1u ? 1u : c2 == 3u ? 2u : c2 == 4u ? 3u : 0u;
-                    } else {
-                        cls = tk_uc_class(t, cp);
                     }
-                }
-                if (PAT && extra) {
-                    const uint64_t xb = (uint64_t)((1u << clen) - 1u) << i;
-                    wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane, (uint32_t)(xb & TKF_WM));
-                    if ((xb >> TKF_W) && lane < 63) wv_lds_or(cl + (2u + extra) * 64u + (uint32_t)lane + 1u, (uint32_t)(xb >> TKF_W));
-                }
-                if (cls != TK_CLS_O) {
-                    const uint64_t bits = (uint64_t)((1u << clen) - 1u) << i;   // may reach into the next lane's word
-                    wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane, (uint32_t)(bits & TKF_WM));
-                    if ((bits >> TKF_W) && lane < 63) wv_lds_or(cl + (cls - 1u) * 64u + (uint32_t)lane + 1u, (uint32_t)(bits >> TKF_W));
-                    if (cls == TK_CLS_N) nmb = true;
+                    mark(i, clen, cls, extra);
+                } else {
+                    // two chars per round, their class words requested together: ONE load each from the trie flattened for the
+                    // BMP (two dependent loads through the two-stage trie, one char at a time, were half of this kernel's time
+                    // on mixed UTF-8 text); a char beyond the BMP walks the trie
+                    const int i0 = __builtin_ctz(w);
+                    w &= w - 1u;
+                    const bool two = w != 0u;
+                    const int i1 = two ? __builtin_ctz(w) : i0;
+                    w &= w - 1u;                          // (w == 0 stays 0)
+                    uint32_t l0, l1;
+                    const uint32_t cp0 = decode(i0, &l0), cp1 = decode(i1, &l1);
+                    const uint32_t q0 = cp0 < 0x10000u ? cp0 : 0u, q1 = cp1 < 0x10000u ? cp1 : 0u;
+                    uint32_t w0 = t.uc_bmp[q0 >> 4], w1 = t.uc_bmp[q1 >> 4];
+                    WV_PIN(w0); WV_PIN(w1);
+                    uint32_t c0 = (w0 >> (2u * (q0 & 15u))) & 3u, c1 = (w1 >> (2u * (q1 & 15u))) & 3u;
+                    if (cp0 >= 0x10000u) c0 = cp0 == 0xFFFFFFFFu ? (uint32_t)TK_CLS_O : tk_uc_class(t, cp0);
+                    if (cp1 >= 0x10000u) c1 = cp1 == 0xFFFFFFFFu ? (uint32_t)TK_CLS_O : tk_uc_class(t, cp1);
+                    mark(i0, l0, c0, 0u);
+                    if (two) mark(i1, l1, c1, 0u);
                 }
             }
         }
@@ -708,9 +734,11 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 f_lo = (uint32_t)TKF_W * (uint32_t)fl + (uint32_t)__builtin_ctz(wv_readlane(PS, fl));
             }
         }
+        uint32_t LMc = 0;
         if (f_lo >= (uint32_t)ca + 64u) {
             const int lo = ca - TKF_W * lane, hi = (int)f_lo - TKF_W * lane;
-            LM |= tkf_lowmask32(hi < 0 ? 0 : hi) & ~tkf_lowmask32(lo < 0 ? 0 : lo);
+            LMc = tkf_lowmask32(hi < 0 ? 0 : hi) & ~tkf_lowmask32(lo < 0 ? 0 : lo);
+            LM |= LMc;
         }
         const uint32_t ge_cb = ~tkf_lowmask32(cb - TKF_W * lane < 0 ? 0 : cb - TKF_W * lane);
         const bool closed = tkf_any(PS & ge_cb);            // the piece that crosses the commit end ends inside the region
@@ -735,6 +763,14 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             }
         }
         FS = LM & ~PS & ~K2 & ~TG & ~tkf_shl(TG, 1);
+        // The piece that comes in is taken over only at a cut among the first 64 commit bytes -- the stretch the chunk before
+        // sees as well (its right halo).  Without one that chunk saw no end of its last fragment: either it knows of no cut
+        // at all and has left the WHOLE piece to a long-piece record (then every byte of it here is foreign, later cuts
+        // included), or it has flagged the document.
+        if (tkf_any(LMc)) {
+            const uint32_t win = ((uint32_t)lane == (uint32_t)TKF_NHL || (uint32_t)lane == (uint32_t)TKF_NHL + 1u) ? TKF_WM : 0u;
+            if (!tkf_any(FS & LMc & win)) { FS &= ~LMc; LM &= ~LMc; }
+        }
         PS |= FS;
         if (closed) own_mask |= LM & ge_cb;
         lds[TKF_L_FS + lane] = FS;
@@ -754,7 +790,6 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         np_all = tot & 0xFFFFu; np_own = tot >> 16;
     }
     const int npass = (TKF_W == 32 && np_all > TKF_MAXPIECES) ? 2 : 1;
-    const uint8_t* rbytes = a.bytes + r0;                   // region byte p is rbytes[p] (only touched inside [0, n))
     uint32_t* tmp = a.tmp + c * TKF_STRIDE;
     uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
     uint32_t E = 0;                                         // slots beyond one per piece so far
@@ -893,13 +928,9 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 if (!PAT && have_ctl && (lopen || len <= TKF_LONGCAP) && !(CUT && frag && lopen)) lres = lopen ? TKF_LONGCAP : len;
                 else toolong = true;                        // (a fragment whose end the region does not show: no cut in 64 bytes)
             } else if (len > 16u && !(DBG && (a.dbg_ablate & 1)) && !(CUT && frag)) {
-                uint32_t h1 = 0, h2 = 0;                    // H = sum b_j P^(len-1-j)
-                for (uint32_t q = 0; q < len; ++q) {
-                    const uint32_t b = rbytes[pos + q];
-                    h1 = h1 * TK_POLY_P1 + b;
-                    h2 = h2 * TK_POLY_P2 + b;
-                }
-                r = tk_probe_long(t, h1, h2, len, rbytes + pos);
+                // 17..64 bytes: KEY64, the piece's dwords from the LDS copy of the region (the polynomial byte hash of LONG,
+                // two multiplies and a global load per byte, was 44 % of this kernel on mixed UTF-8 text, whose words are long)
+                r = tk_probe_key64(t, lds + TKF_L_TXT + (pos >> 2), pos & 3u, len);
             }
             if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
             if (wv_ballot(lres != 0u)) {

@@ -41,6 +41,38 @@ void TkHostTables::make_pair_filter() {
 // boundary between bytes i-1 and i is a vocabulary key -- of two bytes (then it is the bigram itself: cut_k2) or of more
 // (then it contains b[i-2..i] or b[i-1..i+1]: cut_g3 holds every trigram that occurs inside a token).
 void TkHostTables::make_cut_tables() {
+    // (also: the two-stage class trie flattened for the BMP -- the flat kernel classifies a multi-byte char with one load)
+    uc_bmp.assign(4096, 0u);
+    for (uint32_t cp = 0; cp < 0x10000u; ++cp) {
+        const uint32_t blk = uc_stage1[cp >> 7];
+        const uint32_t w = uc_stage2[blk * 8u + ((cp & 127u) >> 4)];
+        uc_bmp[cp >> 4] |= ((w >> (2u * (cp & 15u))) & 3u) << (2u * (cp & 15u));
+    }
+    // KEY64: the tokens of 17..64 bytes by the dword hash of the flat kernel (tk_hash.h)
+    {
+        uint64_t n64 = 0;
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            const uint32_t len = offs[r + 1] - offs[r];
+            if (len >= 17u && len <= 64u) ++n64;
+        }
+        const uint32_t cap = pow2_at_least(2 * n64 + 1);
+        key64_mask = cap - 1;
+        key64_tab.assign(cap, tk_long_entry{0, 0, 0, 0});
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            const uint8_t* p = blob.data() + offs[r];
+            const uint32_t len = offs[r + 1] - offs[r];
+            if (len < 17u || len > 64u) continue;
+            uint32_t ha = 0, hb = 0;
+            for (uint32_t j = 0; j < len; j += 4) {
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < 4 && j + k < len; ++k) w |= (uint32_t)p[j + k] << (8 * k);
+                tk_k64_step(ha, hb, w);
+            }
+            uint32_t sl = tk_k64_slot(ha, len) & key64_mask;
+            while (key64_tab[sl].len) sl = (sl + 1) & key64_mask;
+            key64_tab[sl] = tk_long_entry{hb, r, len, offs[r]};
+        }
+    }
     cut_k2.assign(TK_CUT_K2_WORDS, 0u);
     cut_g3.assign(TK_CUT_G3_WORDS, 0u);
     for (uint32_t r = 0; r < n_ranks; ++r) {
@@ -69,6 +101,9 @@ TkTablesView TkHostTables::host_view() const {
     v.pair_tab = pair_tab.data();
     v.pair2 = pair2.data();
     v.pair_filter = pair_filter.data();
+    v.uc_bmp = uc_bmp.data();
+    v.key64_tab = key64_tab.data();
+    v.key64_mask = key64_mask;
     v.cut_k2 = cut_k2.data();
     v.cut_g3 = cut_g3.data();
     v.blob = blob.data();

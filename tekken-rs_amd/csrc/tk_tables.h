@@ -25,6 +25,9 @@ struct TkTablesView {
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
     const uint32_t* pair_filter;     // [TK_PAIRF_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab (tk_hash.h)
+    const tk_long_entry* key64_tab;  // whole pieces of 17..64 bytes, hashed by dwords (tk_hash.h KEY64): the flat kernel's look-up
+    uint32_t key64_mask;
+    const uint32_t* uc_bmp;          // [4096] the class trie flattened for the BMP: 16 x 2-bit classes per word, word cp >> 4 (ONE load per char)
     const uint32_t* cut_k2;          // [TK_CUT_K2_WORDS] bit (b0 | b1 << 8): the two bytes are a vocabulary KEY (cut rule, tk_hash.h)
     const uint32_t* cut_g3;          // [TK_CUT_G3_WORDS] bit (b0 | b1 << 8 | b2 << 16): the trigram occurs inside some token
     const uint8_t* blob;             // token bytes, for verifying LONG hits
@@ -48,6 +51,9 @@ struct TkHostTables {
     std::vector<uint32_t> pair2;
     std::vector<uint32_t> pair_filter;  // derived from pair_tab (make_pair_filter), not part of the table cache
     std::vector<uint32_t> cut_k2, cut_g3;   // the cut rule's bit maps, derived from blob / offs (make_cut_tables), not part of the table cache
+    std::vector<uint32_t> uc_bmp;           // derived from the trie (make_cut_tables)
+    std::vector<tk_long_entry> key64_tab;   // derived from blob / offs (make_cut_tables)
+    uint32_t key64_mask = 0;
     uint32_t key8_mask = 0, key_mask = 0, long_mask = 0, pair_mask = 0, key_hash_mode = 0;
     uint32_t n_ranks = 0, num_special = 0, bos_id = 0, eos_id = 0;
     uint32_t p1inv = 0, p2inv = 0;

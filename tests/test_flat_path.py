@@ -141,6 +141,12 @@ def test_emu_cut_decomposition(test_vocab):
     assert _emu_check(test_vocab, docs) == []
     for bos, eos in ((False, False), (True, False)):
         _emu_check(test_vocab, docs[:12], bos, eos)
+    # a piece without a cut in the stretch two chunks share (the first 64 bytes behind a commit boundary) belongs to ONE of them:
+    # 131 x 't' + 'm' from commit offset 1914 on -- the only cut (before the 'm') lies 93 bytes into the next chunk, which must
+    # leave the whole piece to the long-piece record of the chunk it starts in (found by tools/gpu_fuzz_long.py: the 'm' came twice)
+    for k in range(1890, 1960, 3):
+        for run in (100, 131, 180, 250):
+            _emu_check(test_vocab, [filler[:k] + b" " + b"t" * run + b"m" + "٣٣٣٣٣中中中".encode() + b" " + filler[:100]], check_split=False)
     n_docs = n_flagged = 0
     for alphabet, n_extra, max_len in (("ab", 60, 6), ("abc", 250, 5), ("abcdefgh", 300, 5), ("aé中", 90, 4), ("abcdefghijklmnop", 200, 4), ("ab \n", 40, 5)):
         toks = gg.vocab_adversarial(rng, alphabet, n_extra, max_len)

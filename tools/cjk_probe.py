@@ -47,8 +47,8 @@ def main():
         sample = 2000
         eids, eoo = orc.encode_batch(data[:int(offs[sample])], offs[:sample + 1], True, True, threads=8)
         ok = bool(np.array_equal(ids[:int(oo[sample])], eids))
-        print("runs of 5..%d ideographs (<= %d bytes): %d docs, %.1f MB, pipeline %.2f ms = %.1f GB/s, handed-back docs %s, bit-exact on %d docs: %s"
-              % (max_run, 3 * max_run, n_docs, len(data) / 1e6, best, len(data) / best / 1e6, t["handed_back"], sample, ok), flush=True)
+        print("runs of 5..%d ideographs (<= %d bytes): %d docs, %.1f MB, pipeline %.2f ms = %.1f GB/s, handed-back docs %s, long-piece records %d, regions through the cut path %d, bit-exact on %d docs: %s"
+              % (max_run, 3 * max_run, n_docs, len(data) / 1e6, best, len(data) / best / 1e6, t["handed_back"], e.long_piece_records(), e.cut_chunks(), sample, ok), flush=True)
     e.close()
 
 

@@ -26,11 +26,16 @@ def make_doc(rng):
     parts = []
     for _ in range(rng.randint(0, rng.choice([3, 12, 60, 400]))):
         c = rng.choice(ALPHA)
-        k = rng.choice([1, 1, 1, 1, 2, 3, 5, 9, 17, 33, 65, 100, 129, 200, 257, 300])
+        k = rng.choice([1, 1, 1, 1, 2, 3, 5, 9, 17, 33, 65, 100, 129, 200, 257, 300, 700, 2100, 4500])   # (beyond 64 bytes: the cut path)
         if k > 3:
             k = rng.randint(k // 2 + 1, k)
-        if rng.random() < 0.5:
+        u = rng.random()
+        if u < 0.4:
             parts.append(c * k)
+        elif u < 0.6:
+            parts.append("".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(k)))   # random letters: cut into fragments
+        elif u < 0.7:
+            parts.append("".join(rng.choice("ab") for _ in range(k)))                           # few distinct pairs: hardly any cut
         else:
             parts.append("".join(rng.choice(ALPHA[:12] + ["中", "文", "é"]) for _ in range(k)))
     return "".join(parts).encode("utf-8")
@@ -46,7 +51,7 @@ def main():
                (tk.Engine(small["tokens"], small["num_special"], small["bos"], small["eos"], device=0), helpers.oracle_for(small), "small vocabulary")]
     rng = random.Random(seed)
     t0 = time.time()
-    batches = docs_total = bytes_total = recs = handed = 0
+    batches = docs_total = bytes_total = recs = handed = cuts = late = 0
     while time.time() - t0 < seconds:
         docs = [make_doc(rng) for _ in range(rng.choice([1, 7, 300, 3000]))]
         data, offs = tk.pack_docs(docs)
@@ -61,12 +66,14 @@ def main():
                         print("MISMATCH (%s) seed %d batch %d doc %d: %r" % (name, seed, batches, d, docs[d][:300]), flush=True)
                         sys.exit(1)
             recs += eng.long_piece_records()
+            cuts += eng.cut_chunks()
+            late += 1 if eng.last_host_syncs() > 2 else 0
             handed += eng.last_stats()["handed_back"]
         batches += 1
         docs_total += len(docs)
         bytes_total += len(data)
-    print("gpu_fuzz_long: %d batches, %d documents, %.1f MB, both vocabularies: bit-exact; %d long-piece records, %d documents handed back (seed %d, %.0f s)"
-          % (batches, docs_total, bytes_total / 1e6, recs, handed, seed, time.time() - t0), flush=True)
+    print("gpu_fuzz_long: %d batches, %d documents, %.1f MB, both vocabularies: bit-exact; %d long-piece records, %d regions through the cut path, %d documents handed back, %d calls with late-flagged documents (seed %d, %.0f s)"
+          % (batches, docs_total, bytes_total / 1e6, recs, cuts, handed, late, seed, time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,15 @@
+#!/bin/bash
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $root
+out=$root/gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q > $out/r03_tests.log 2>&1 || { tail -40 $out/r03_tests.log; exit 1; }
+tail -1 $out/r03_tests.log
+timeout -k 10 500 python tools/gpu_fuzz_long.py 200 31 > $out/r03_fuzz_long.txt 2>&1 || { tail -5 $out/r03_fuzz_long.txt; exit 1; }
+tail -1 $out/r03_fuzz_long.txt
+timeout -k 10 500 python tools/gpu_fuzz_long.py 100 77 >> $out/r03_fuzz_long.txt 2>&1 || { tail -5 $out/r03_fuzz_long.txt; exit 1; }
+tail -1 $out/r03_fuzz_long.txt
+timeout -k 10 300 python tools/gpu_fuzz.py 100 32 > $out/r03_fuzz.txt 2>&1 || { tail -5 $out/r03_fuzz.txt; exit 1; }
+tail -1 $out/r03_fuzz.txt
+(echo "== cut decomposition on (default)"; timeout -k 10 300 python tools/cjk_probe.py 100000; echo "== TK_FLAT_CUT=0"; TK_FLAT_CUT=0 timeout -k 10 300 python tools/cjk_probe.py 100000) > $out/r03_cjk_probe.txt 2>&1 || { tail -5 $out/r03_cjk_probe.txt; exit 1; }
+cat $out/r03_cjk_probe.txt
+bash tools/quick_merge.sh

@@ -46,39 +46,56 @@ CONFIG_OF_KIND = {"ascii": ("configs[1]", "configs[3]"), "mixed": ("configs[2]",
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (one per GPU) and relay rank 0's
-    JSON line.  Runs BEFORE torch / HIP is touched in this process (a process that has initialised the GPU must never
-    be replaced or forked into ranks); the children are ordinary child processes, their exit codes are ours."""
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as ordinary child processes.  Runs BEFORE anything in
+    this process touches the GPU (no torch import, no HIP call): the children are plain subprocesses, nothing is re-executed.
+    The children are watched together: when one of them dies the others are stopped at once (a rank that waits in a collective
+    for a dead peer would otherwise sit there until the collective's own time-out), and the whole launch has a time limit."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0 prints the line; the other ranks keep their stderr (a failing rank must be able to say why) but not their stdout
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # (rank 0 never blocks on a full pipe)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("TK_BENCH_LAUNCH_TIMEOUT", "3000"))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = "rank %d exited with code %d" % (r, p.returncode)
+        if failed is None and time.time() > deadline:
+            failed = "the ranks did not finish in time"
+        if failed is None:
+            time.sleep(0.2)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = "rank %d exited with code %d" % (r, p.returncode)
+    if failed is not None:
+        for p in procs:                      # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit("bench.py --gpus %d: %s; the other ranks were stopped" % (args.gpus, failed))
+    reader.join(timeout=30)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("[bench] ranks failed: %r\n" % (bad,))
-        raise SystemExit(1)
     raise SystemExit(0)
-
-
-def build_info():
-    """git commit the library was built at (written by __graft_entry__.build(); the GPU box has no .git)."""
-    try:
-        with open(os.path.join(ROOT, "tekken-rs_amd", "BUILD_INFO.json")) as f:
-            return json.load(f)
-    except Exception:  # noqa: BLE001
-        return {"git": None}
 
 
 def main():
@@ -92,6 +109,8 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--vocab-fit", choices=["same", "heldout"], default="same",
+                    help="synthetic vocabulary: trained on the corpus's whole word list (same) or with ~15 %% of its word occurrences withheld (heldout)")
     ap.add_argument("--gather", choices=["overlap", "sync"], default="overlap",
                     help="N > 1: gather of batch k beside the kernels of batch k + 1 (default) or inside the step, blocking")
     ap.add_argument("--wire", type=int, choices=[18, 32], default=18, help="N > 1: bits per id on the wire")
@@ -136,8 +155,14 @@ def main():
     xdev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the collectives' tensors live
 
     # ---- vocabulary (real tekken.json if TEKKEN_JSON is set, else the seeded synthetic one) ----
-    vocab_path = args.vocab or sv.ensure_default()
-    vocab_kind = "tekken.json" if args.vocab else "synthetic-130072"
+    if args.vocab:
+        vocab_path, vocab_kind = args.vocab, "tekken.json"
+    elif args.vocab_fit == "heldout":
+        # a vocabulary that never saw ~15 % of the corpus's word occurrences (tools/synth_vocab.py heldout_words): the miss rate
+        # of a real vocabulary on real text, not the 2.4 % of one trained on the very word list the corpus draws from
+        vocab_path, vocab_kind = sv.ensure_heldout(), "synthetic-130072-heldout"
+    else:
+        vocab_path, vocab_kind = sv.ensure_default(), "synthetic-130072"
     tokz = tk.Tekkenizer.from_file(vocab_path, device=local_rank)  # loader + table build + upload
     eng = tokz.engine()
 

@@ -532,17 +532,30 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
     uint64_t n_bytes = offs[n_docs];
     /* the staging buffer is kept between calls (grown on demand): a fresh 2 GB malloc per call is 500 k page faults that
        256 threads take on one address space -- the second pass of a timing run then measures the encode, not the kernel's mm */
+    /* (one call at a time uses the kept buffers: the bindings release the GIL, two N-thread calls of one process are serialised here) */
+    static pthread_mutex_t g_stage_mu = PTHREAD_MUTEX_INITIALIZER;
     static uint32_t* g_stage = NULL; static uint64_t g_stage_cap = 0;
     static uint32_t* g_counts = NULL; static uint64_t g_counts_cap = 0;
+    pthread_mutex_lock(&g_stage_mu);
     if (g_stage_cap < n_bytes + 2 * n_docs + 1) { free(g_stage); g_stage_cap = n_bytes + 2 * n_docs + 1; g_stage = (uint32_t*)malloc(sizeof(uint32_t) * g_stage_cap); }
     if (g_counts_cap < n_docs + 1) { free(g_counts); g_counts_cap = n_docs + 1; g_counts = (uint32_t*)malloc(sizeof(uint32_t) * g_counts_cap); }
     uint32_t* stage = g_stage;
     uint32_t* counts = g_counts;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
     job_t* jobs = (job_t*)malloc(sizeof(job_t) * n_threads);
+    /* contiguous document ranges cut by BYTES, like the GPU side shards (by document count the thread that draws the 32 KiB
+       documents of the Zipf shape finishes long after the others and the N-thread baseline is understated) */
+    uint64_t d_lo = 0;
     for (int i = 0; i < n_threads; ++i) {
-        jobs[i] = (job_t){o, bytes, offs, n_docs * i / n_threads, n_docs * (i + 1) / n_threads,
-                          add_bos, add_eos, stage, counts, out_ids, out_offs};
+        uint64_t d_hi = n_docs;
+        if (i + 1 < n_threads) {
+            const uint64_t want = offs[0] + (n_bytes - offs[0]) / (uint64_t)n_threads * (uint64_t)(i + 1);
+            uint64_t lo = d_lo, hi = n_docs;              /* first document that starts at or beyond `want` */
+            while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (offs[mid] < want) lo = mid + 1; else hi = mid; }
+            d_hi = lo;
+        }
+        jobs[i] = (job_t){o, bytes, offs, d_lo, d_hi, add_bos, add_eos, stage, counts, out_ids, out_offs};
+        d_lo = d_hi;
         pthread_create(&th[i], NULL, job_main, &jobs[i]);
     }
     for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
@@ -552,6 +565,7 @@ uint64_t tk_oracle_encode_batch(const tk_oracle* o, const uint8_t* bytes, const 
     for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, pack_main, &jobs[i]);
     for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
     free(th); free(jobs);
+    pthread_mutex_unlock(&g_stage_mu);
     g_last_batch_seconds = now_seconds() - t_begin;
     return t;
 }

@@ -164,6 +164,7 @@ struct tk_ctx {
     void* ds_out = nullptr;
     DevBuf s_offs;
     uint64_t n_small_calls = 0;    // calls served by the one-launch path (tk_last_stats_ex)
+    bool small_ready = false;      // small_prepare() went through completely
 };
 
 #define TK_SMALL_IDS_CAP (TK_SMALL_MAX_BYTES + 2 * TK_SMALL_MAX_DOCS)
@@ -285,7 +286,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     if (const char* fl = getenv("TK_FLAT_CUT")) c->no_flat_cut = atoi(fl) == 0;
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
     if (const char* lz = getenv("TK_LONG_LAZY_MUL")) c->long_lazy_mul = (uint32_t)atoi(lz);
-    if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 65 = every piece beyond a window
+    if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 1 = every long piece through the compacting rounds, 2 = through the lazy rounds
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
         c->pipeline_forced = strcmp(pl, "doc") == 0 ? 2 : strcmp(pl, "flat") == 0 ? 1 : 0;
     *out_ctx = c;
@@ -762,6 +763,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         }
         rc = finish(1, true);
         if (rc != TK_OK) return rc;
+        if (c->h_pin[5] == 0xDEADu) { c->err = "internal: the long-piece job list overflowed"; return TK_ERR_RUNTIME; }   // (set by tk_long_walk_kernel)
         c->n_long_docs = c->pattern == 1 ? n_todo : c->h_pin[1];
         c->n_round_docs += n_todo && c->long_min ? c->h_pin[10] : 0;   // (here: long pieces merged in rounds)
         const uint32_t n_late = n_lrec ? c->h_pin[15] : 0;
@@ -907,17 +909,20 @@ static bool small_eligible(const tk_ctx* c, uint64_t n_docs, uint64_t n_bytes) {
 }
 
 static int small_prepare(tk_ctx* c) {
-    if (c->hs_in) return TK_OK;
+    if (c->small_ready) return TK_OK;
+    // (ready only once EVERY step below went through: a call that fails half-way leaves the flag clear, and the next call
+    // starts over with what is still missing instead of running on null pointers)
     const size_t in_bytes = TK_SMALL_MAX_BYTES + (TK_SMALL_MAX_DOCS + 1) * 8;
     const size_t out_bytes = (size_t)(TK_SMALL_STATUS_WORD + 4) * 4;
-    TK_HIP(c, hipHostMalloc((void**)&c->hs_in, in_bytes, hipHostMallocMapped));
-    TK_HIP(c, hipHostMalloc((void**)&c->hs_out, out_bytes, hipHostMallocMapped));
+    if (!c->hs_in) TK_HIP(c, hipHostMalloc((void**)&c->hs_in, in_bytes, hipHostMallocMapped));
+    if (!c->hs_out) TK_HIP(c, hipHostMalloc((void**)&c->hs_out, out_bytes, hipHostMallocMapped));
     TK_HIP(c, hipHostGetDevicePointer(&c->ds_in, c->hs_in, 0));
     TK_HIP(c, hipHostGetDevicePointer(&c->ds_out, c->hs_out, 0));
     TK_HIP(c, c->staging.reserve((size_t)(TK_SMALL_IDS_CAP + 64) * 4));
     TK_HIP(c, c->counts.reserve((TK_SMALL_MAX_DOCS + 1) * 4));
     TK_HIP(c, c->in_bytes.reserve(TK_SMALL_MAX_BYTES + 64));
     TK_HIP(c, c->s_offs.reserve((TK_SMALL_MAX_DOCS + 1) * 8));
+    c->small_ready = true;
     return TK_OK;
 }
 

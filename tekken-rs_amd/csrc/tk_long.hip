@@ -609,6 +609,10 @@ __global__ __launch_bounds__(256) void tk_long_walk_kernel(TkEncodeArgs a) {
                         TkLongJob j;
                         j.doc = (uint32_t)d; j.off = (uint32_t)(w0 - s0); j.len = len; j.pad = kind;
                         a.long_jobs[slot] = j;
+                    } else if (a.defer_count) {
+                        // cannot happen with the host's sizing (a job is at least long_min bytes of text); if it ever does the
+                        // piece's slots stay unwritten, so the call must fail loudly: an error word the host checks
+                        *a.defer_count = 0xDEADu;
                     }
                 }
                 cur = len;                                         // (its slots are written by tk_long_merge_kernel)

@@ -32,10 +32,21 @@ SPECIAL_NAMES = ["<unk>", "<s>", "</s>", "[INST]", "[/INST]", "[AVAILABLE_TOOLS]
                  "[PREFIX]", "[MIDDLE]", "[SUFFIX]", "[SYSTEM_PROMPT]", "[/SYSTEM_PROMPT]", "[TOOL_CONTENT]"]
 
 
-def piece_counts(n_ascii_docs, n_mixed_docs, seed):
+def heldout_words():
+    """The words of the generator's 4 096-word list that the HELD-OUT vocabulary never sees: every fourth word from index 19
+    on (about 15 % of the word occurrences of G-ascii by Zipf mass).  bench.py --vocab-fit heldout tokenizes the ordinary
+    corpus with that vocabulary: its words routinely take several tokens, like `tokenizer`, `decoding`, `comparison` in the
+    reference's own vectors (tests/test_tokenizer_output.rs:217, 251, 268), and the merge kernels see a realistic miss rate
+    instead of the 2.4 % of a vocabulary trained on the very word list the corpus draws from."""
+    import corpus
+    return {w for i, w in enumerate(corpus.words()) if i >= 16 and i % 4 == 3}
+
+
+def piece_counts(n_ascii_docs, n_mixed_docs, seed, heldout=False):
     import corpus
     import tk_oracle
     cnt = collections.Counter()
+    held = heldout_words() if heldout else set()
     for kind, n, dl, sd in (("ascii", n_ascii_docs, 512, seed + 101), ("mixed", n_mixed_docs, 2048, seed + 102)):
         if n == 0:
             continue
@@ -43,7 +54,10 @@ def piece_counts(n_ascii_docs, n_mixed_docs, seed):
         raw = data.tobytes()
         for d in range(n):
             doc = raw[int(offs[d]):int(offs[d + 1])]
-            cnt.update(tk_oracle.split_pieces(doc))
+            pieces = tk_oracle.split_pieces(doc)
+            if held:
+                pieces = [p for p in pieces if bytes(c for c in p.lower() if 97 <= c <= 122).decode() not in held]
+            cnt.update(pieces)
     return cnt
 
 
@@ -144,8 +158,8 @@ def grow(tokens, n_ranks, rng):
     return tokens
 
 
-def build_tokens(n_ranks, n_merges, n_ascii_docs, n_mixed_docs, seed):
-    cnt = piece_counts(n_ascii_docs, n_mixed_docs, seed)
+def build_tokens(n_ranks, n_merges, n_ascii_docs, n_mixed_docs, seed, heldout=False):
+    cnt = piece_counts(n_ascii_docs, n_mixed_docs, seed, heldout)
     merges = train_bpe(cnt, min(n_merges, max(0, n_ranks - 256)))
     tokens = [bytes([i]) for i in range(256)] + merges
     tokens = grow(tokens, n_ranks, random.Random(seed))
@@ -186,6 +200,18 @@ def ensure_default(path=None, n_ranks=130072, n_merges=40000, n_ascii_docs=20000
     path = path or default_path()
     if not os.path.exists(path):
         write_json(path, build_tokens(n_ranks, n_merges, n_ascii_docs, n_mixed_docs, seed))
+    return path
+
+
+def heldout_path():
+    return os.path.join(ROOT, "assets", "synth_tekken_heldout.json")
+
+
+def ensure_heldout(path=None, n_ranks=130072, n_merges=40000, n_ascii_docs=20000, n_mixed_docs=3000, seed=0x7E44E2):
+    """The same construction with heldout_words() withheld from the training pieces."""
+    path = path or heldout_path()
+    if not os.path.exists(path):
+        write_json(path, build_tokens(n_ranks, n_merges, n_ascii_docs, n_mixed_docs, seed, heldout=True))
     return path
 
 

@@ -98,6 +98,15 @@ def self_launch(args):
     raise SystemExit(0)
 
 
+def build_info():
+    """git commit the library was built at (written by __graft_entry__.build(); the GPU box has no .git)."""
+    try:
+        with open(os.path.join(ROOT, "tekken-rs_amd", "BUILD_INFO.json")) as f:
+            return json.load(f)
+    except Exception:  # noqa: BLE001
+        return {"git": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +118,9 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=3, help="oracle passes over the CPU sample (0 = skip)")
     ap.add_argument("--cpu-sample-docs", type=int, default=1_000_000)
     ap.add_argument("--vocab", default=os.environ.get("TEKKEN_JSON", ""))
+    ap.add_argument("--entry", choices=["ranks", "node"], default="ranks",
+                    help="ranks: one process per GPU (torch.distributed, what the driver launches); node: ONE process, the C ABI's "
+                         "tk_node_* over GPUs 0..N-1 with pinned host buffers -- what a Rust host calls (PCIe inclusive: never `value` of the contract)")
     ap.add_argument("--vocab-fit", choices=["same", "heldout"], default="same",
                     help="synthetic vocabulary: trained on the corpus's whole word list (same) or with ~15 %% of its word occurrences withheld (heldout)")
     ap.add_argument("--gather", choices=["overlap", "sync"], default="overlap",
@@ -123,6 +135,8 @@ def main():
     args = ap.parse_args()
     if args.steps <= 0:
         args.steps = 400 if args.kind == "ascii" else 30
+    if args.entry == "node":
+        return node_entry(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("TK_BENCH_FORCE_DIST") != "1":
         self_launch(args)
 
@@ -347,6 +361,58 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     tokz.close()
+
+
+def node_entry(args):
+    """`--entry node`: the native multi-GPU entry a Rust / C host calls (tk_node_create over GPUs 0..N-1, one process, one host
+    thread per device, documents sharded whole by bytes, ONE RCCL gather of the id buffers to GPU 0; csrc/tk_node.cpp), with
+    pinned caller buffers (tk_node_encode_batch_pinned).  Host buffers in, host buffers out: the figure includes PCIe both ways
+    and the gather -- it is reported under its own metric name, beside the slowest device's kernel time and the exchange time
+    from tk_node_last_timing.  Weak scaling: --docs documents per GPU."""
+    import importlib
+    import time
+    import numpy as np
+    import corpus
+    import synth_vocab as sv
+    import tk_oracle
+    tk = importlib.import_module("tekken-rs_amd")
+    vocab_path = args.vocab or (sv.ensure_heldout() if args.vocab_fit == "heldout" else sv.ensure_default())
+    toks, ns, bos, eos = sv.load_tokens(vocab_path)
+    n = args.gpus
+    n_docs = args.docs * n
+    data, offs = corpus.generate(args.kind, n_docs, args.doc_len, seed=corpus.BASE_SEED + 1)
+    h_data, h_offs = tk.host_empty(len(data), np.uint8), tk.host_empty(len(offs), np.uint64)
+    h_data[:] = data
+    h_offs[:] = offs
+    h_ids, h_oo = tk.host_empty(len(data) + 2 * len(offs), np.uint32), tk.host_empty(len(offs), np.uint64)
+    node = tk.Node(toks, ns, bos, eos, devices=tuple(range(n)))
+    for _ in range(max(args.warmup, 1)):
+        n_ids = node.encode_batch_into(h_data, h_offs, h_ids, h_oo, True, True)
+    k_ms, g_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_ids = node.encode_batch_into(h_data, h_offs, h_ids, h_oo, True, True)
+        t = node.last_timing()
+        k_ms.append(t["kernels_ms_max"])
+        g_ms.append(t["gather_ms"])
+    elapsed = time.perf_counter() - t0
+    # parity on a sample through the oracle (the checker), ids in document order as from one GPU
+    sample = min(n_docs, 20000)
+    orc = tk_oracle.Oracle(toks, ns, bos, eos)
+    eids, eoo = orc.encode_batch(data[:int(offs[sample])], offs[:sample + 1], True, True, threads=16)
+    exact = bool(np.array_equal(h_ids[:int(h_oo[sample])], eids) and np.array_equal(h_oo[:sample + 1], eoo))
+    ms = elapsed / args.steps * 1e3
+    print(json.dumps({
+        "metric": "input MB/s tokenized (whole node), host buffers in -> ids in host buffers (PCIe and gather inclusive; tk_node_encode_batch_pinned)",
+        "value": round(len(data) / 1e6 / (ms * 1e-3), 1), "unit": "MB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%d x %s documents per GPU, one process, tk_node_* over GPUs 0..%d, pinned caller buffers" % (args.docs, args.kind, n - 1),
+                   "entry": "node", "docs_total": n_docs, "input_bytes_total": int(len(data)), "ids_total": int(n_ids)},
+        "node": {"kernels_ms_max": round(float(np.mean(k_ms)), 4), "gather_ms": round(float(np.mean(g_ms)), 4)},
+        "bit_exact_vs_cpu_sample_docs": sample, "bit_exact_vs_cpu": exact, "build": build_info()}), flush=True)
+    node.close()
+    if not exact:
+        raise SystemExit(1)
 
 
 def host_leg(args, tk, eng, data, offs, h_ids, h_oo):

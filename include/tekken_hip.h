@@ -180,7 +180,7 @@ int tk_unpack_ids18_device(tk_ctx* ctx, const void* d_packed, uint64_t n_ids, vo
  * Node level: every GPU of one node behind ONE call (no reference equivalent: the reference is one thread on a CPU;
  * BASELINE north_star "shards ... across the 8xMI355X node with a single RCCL gather of token-id buffers over xGMI";
  * SURVEY section 8b `ctx_create(.., device_ids[], n_devices, ..)`).  One process; per device one context (tables
- * replicated), one stream, one host thread per call.  tk_node_encode_batch cuts the batch into contiguous runs of WHOLE
+ * replicated), one stream, one host thread for the life of the node.  tk_node_encode_batch cuts the batch into contiguous runs of WHOLE
  * documents with balanced bytes, every device tokenizes its run, and the id buffers are gathered on device_ids[0] with
  * direct peer -> root RCCL transfers inside one ncclGroupStart / ncclGroupEnd (18 bits per id on the wire when every id
  * fits) -- for every document exactly what Tekkenizer::encode returns (src/tekkenizer.rs:378-405), in document order.
@@ -194,6 +194,12 @@ void tk_node_destroy(tk_node* node);
 const char* tk_node_last_error(const tk_node* node);
 int tk_node_encode_batch(tk_node* node, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
                          int add_eos, tk_result* out);
+/* The same with CALLER-OWNED host buffers: ids_out[ids_capacity], offsets_out[n_docs + 1]; *n_ids_out = ids written (also set
+ * when ids_capacity is too small: TK_ERR_INVALID_ARG, nothing written).  With every buffer from tk_host_alloc (pinned) the
+ * copies up and down are asynchronous DMAs and nothing is allocated, pinned or copied on the host per call -- the form a
+ * host that encodes batch after batch should use (the Rust shim's encode_batch_into). */
+int tk_node_encode_batch_pinned(tk_node* node, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
+                                int add_eos, uint32_t* ids_out, uint64_t ids_capacity, uint64_t* offsets_out, uint64_t* n_ids_out);
 int tk_node_n_devices(const tk_node* node);
 /* Device timings of the last tk_node_encode_batch: the slowest device's tokenization pipeline, and the exchange on the root
  * (first receive posted .. offsets rebased), milliseconds. */

@@ -67,4 +67,7 @@ extern "C" {
     pub fn tk_node_last_error(node: *const TkNode) -> *const c_char;
     pub fn tk_node_encode_batch(node: *mut TkNode, bytes: *const u8, doc_offsets: *const u64, n_docs: u64, add_bos: c_int,
                                 add_eos: c_int, out: *mut TkResult) -> c_int;
+    // caller-owned host buffers (tk_host_alloc: pinned -- nothing allocated, pinned or copied on the host per call)
+    pub fn tk_node_encode_batch_pinned(node: *mut TkNode, bytes: *const u8, doc_offsets: *const u64, n_docs: u64, add_bos: c_int,
+                                       add_eos: c_int, ids_out: *mut u32, ids_capacity: u64, offsets_out: *mut u64, n_ids_out: *mut u64) -> c_int;
 }

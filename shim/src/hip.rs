@@ -144,6 +144,22 @@ impl HipNode {
         }
         Ok(unsafe { take(&mut res, docs.len()) })
     }
+
+    /// The batch form for a host that encodes batch after batch: packed text + offsets in, ids + id offsets out, all four in
+    /// buffers the caller keeps (pinned: `tk_host_alloc`) -- returns the number of ids written.
+    pub fn encode_batch_into(&self, bytes: &[u8], doc_offsets: &[u64], add_bos: bool, add_eos: bool, ids_out: &mut [u32],
+                             offsets_out: &mut [u64]) -> Result<usize, HipError> {
+        assert!(!doc_offsets.is_empty() && offsets_out.len() >= doc_offsets.len());
+        let mut n: u64 = 0;
+        let rc = unsafe {
+            tk_node_encode_batch_pinned(self.node, bytes.as_ptr(), doc_offsets.as_ptr(), (doc_offsets.len() - 1) as u64, add_bos as c_int,
+                                        add_eos as c_int, ids_out.as_mut_ptr(), ids_out.len() as u64, offsets_out.as_mut_ptr(), &mut n)
+        };
+        if rc != TK_OK {
+            return Err(map_err(rc, unsafe { tk_node_last_error(self.node) }));
+        }
+        Ok(n as usize)
+    }
 }
 impl Drop for HipNode {
     fn drop(&mut self) {

@@ -207,6 +207,8 @@ def lib():
     L.tk_node_last_error.argtypes = [vp]
     L.tk_node_encode_batch.restype = ctypes.c_int
     L.tk_node_encode_batch.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_Result)]
+    L.tk_node_encode_batch_pinned.restype = ctypes.c_int
+    L.tk_node_encode_batch_pinned.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, ctypes.c_uint64, u64p, u64p]
     L.tk_node_n_devices.restype = ctypes.c_int
     L.tk_node_n_devices.argtypes = [vp]
     L.tk_node_last_timing.restype = ctypes.c_int
@@ -506,6 +508,18 @@ class Node:
         if rc != TK_OK:
             raise TokenizerError(rc, lib().tk_node_last_error(self._h).decode())
         return _take_result(res)
+
+    def encode_batch_into(self, data, offs, ids_out, offs_out, add_bos=True, add_eos=True):
+        """tk_node_encode_batch_pinned: caller-owned buffers (host_empty: pinned -- nothing allocated or pinned per call).  Returns the
+        number of ids written into ids_out; offs_out[: n_docs + 1] holds the id offsets."""
+        assert data.dtype == np.uint8 and offs.dtype == np.uint64 and ids_out.dtype == np.uint32 and offs_out.dtype == np.uint64
+        n = ctypes.c_uint64(0)
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        rc = lib().tk_node_encode_batch_pinned(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1, int(add_bos),
+                                               int(add_eos), _p(ids_out, ctypes.c_uint32), len(ids_out), _p(offs_out, ctypes.c_uint64), ctypes.byref(n))
+        if rc != TK_OK:
+            raise TokenizerError(rc, lib().tk_node_last_error(self._h).decode())
+        return int(n.value)
 
     def last_timing(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)

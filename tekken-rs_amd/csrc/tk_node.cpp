@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -84,6 +86,69 @@ struct DBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// pinned host staging (the run-relative document offsets of a device's shard): kept across calls, grown on demand
+struct HBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// One host thread per device for the life of the node (the first form started and joined a std::thread per device and
+// call): a call hands every worker its job and waits for all of them.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has = false, quit = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return has || quit; });
+                if (quit && !has) return;
+                j = std::move(job);
+            }
+            j();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                has = false;
+            }
+            cv.notify_all();
+        }
+    }
+    void start() { th = std::thread([this] { loop(); }); }
+    void post(std::function<void()> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            has = true;
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !has; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct Shard {
     uint64_t d0 = 0, d1 = 0, b0 = 0, n_bytes = 0;   // documents [d0, d1), bytes from b0
     uint64_t n_ids = 0;
@@ -102,6 +167,8 @@ struct tk_node {
     std::vector<hipStream_t> stream;
     std::vector<ncclComm_t> comm;              // empty when the node runs without RCCL (one device)
     std::vector<DBuf> in_bytes, in_offs, packed;
+    std::vector<HBuf> rel;                     // pinned: run-relative document offsets going up
+    std::vector<Worker*> workers;              // one per device (n > 1)
     std::vector<DBuf> stage;                   // on the root: the peers' payloads as they arrive
     DBuf all_ids, all_offs;                    // on the root: the gathered result
     bool wire18 = false;                       // every id fits 18 bits
@@ -133,6 +200,9 @@ extern "C" const char* tk_node_last_error(const tk_node* nd) { return nd ? nd->e
 
 extern "C" void tk_node_destroy(tk_node* nd) {
     if (!nd) return;
+    for (Worker* w : nd->workers) { w->stop(); delete w; }
+    nd->workers.clear();
+    for (HBuf& h : nd->rel) h.release();
     for (int i = 0; i < (int)nd->comm.size(); ++i)
         if (nd->comm[i]) (void)g_rccl.CommDestroy(nd->comm[i]);
     for (int i = 0; i < nd->n; ++i) {
@@ -166,6 +236,7 @@ extern "C" int tk_node_create(const uint8_t* token_bytes, const uint32_t* token_
     nd->ctx.assign(n_devices, nullptr);
     nd->stream.assign(n_devices, nullptr);
     nd->in_bytes.resize(n_devices); nd->in_offs.resize(n_devices); nd->packed.resize(n_devices); nd->stage.resize(n_devices);
+    nd->rel.resize(n_devices);
     auto fail = [&](int code, const std::string& msg) {
         g_node_tls_err = msg;
         tk_node_destroy(nd);
@@ -193,6 +264,11 @@ extern "C" int tk_node_create(const uint8_t* token_bytes, const uint32_t* token_
             return fail(TK_ERR_RUNTIME, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
         }
     }
+    if (n_devices > 1)
+        for (int i = 0; i < n_devices; ++i) {
+            nd->workers.push_back(new Worker());
+            nd->workers.back()->start();
+        }
     *out_node = nd;
     return TK_OK;
 }
@@ -214,12 +290,10 @@ static std::vector<uint64_t> shard_by_bytes(const uint64_t* offs, uint64_t n_doc
     return cuts;
 }
 
-extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
-                                    int add_eos, tk_result* out) {
-    if (!nd) return TK_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(nd->mu);
-    if (!doc_offsets || !out || (!bytes && doc_offsets[n_docs])) { nd->err = "null argument"; return TK_ERR_INVALID_ARG; }
-    memset(out, 0, sizeof(*out));
+// ids_dst == NULL: the result goes into pinned blocks of the library's pool (tk_free_result); otherwise into the caller's
+// buffers (ids_cap entries, n_docs + 1 offsets)
+static int node_encode(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos, int add_eos,
+                       uint32_t* ids_dst, uint64_t ids_cap, uint64_t* offs_dst, uint32_t** ids_res, uint64_t** offs_res, uint64_t* n_ids_res) {
     if (doc_offsets[0] != 0) { nd->err = "doc_offsets[0] must be 0"; return TK_ERR_INVALID_ARG; }
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_offsets[d + 1] < doc_offsets[d]) { nd->err = "doc_offsets must be non-decreasing"; return TK_ERR_INVALID_ARG; }
@@ -238,14 +312,16 @@ extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uin
         if (e != hipSuccess) return hip_fail("hipSetDevice", e);
         if ((e = nd->in_bytes[k].reserve(s.n_bytes + 64)) != hipSuccess || (e = nd->in_offs[k].reserve((nd_k + 1) * 8)) != hipSuccess)
             return hip_fail("hipMalloc", e);
-        std::vector<uint64_t> rel(nd_k + 1);
+        // (the run-relative offsets in pinned staging that lives as long as the node: both copies are asynchronous DMAs when the
+        // caller's text is pinned too -- tk_host_alloc --, and the encode call below is the one wait)
+        if ((e = nd->rel[k].reserve((nd_k + 1) * 8)) != hipSuccess) return hip_fail("hipHostMalloc", e);
+        uint64_t* rel = (uint64_t*)nd->rel[k].p;
         for (uint64_t d = 0; d <= nd_k; ++d) rel[d] = doc_offsets[s.d0 + d] - s.b0;
         hipStream_t st = nd->stream[k];
         if (s.n_bytes && (e = hipMemcpyAsync(nd->in_bytes[k].p, bytes + s.b0, s.n_bytes, hipMemcpyHostToDevice, st)) != hipSuccess)
             return hip_fail("hipMemcpyAsync", e);
-        if ((e = hipMemcpyAsync(nd->in_offs[k].p, rel.data(), (nd_k + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess)
+        if ((e = hipMemcpyAsync(nd->in_offs[k].p, rel, (nd_k + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess)
             return hip_fail("hipMemcpyAsync", e);
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail("hipStreamSynchronize", e);   // rel goes out of scope
         s.rc = tk_encode_batch_device(nd->ctx[k], nd->in_bytes[k].p, nd->in_offs[k].p, nd_k, s.n_bytes, add_bos, add_eos, st, &s.d_ids,
                                       &s.d_oo, &s.n_ids);
         if (s.rc != TK_OK) { s.err = tk_last_error(nd->ctx[k]); return; }
@@ -259,9 +335,8 @@ extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uin
     if (n == 1) {
         work(0);
     } else {
-        std::vector<std::thread> th;
-        for (int k = 0; k < n; ++k) th.emplace_back(work, k);
-        for (auto& t : th) t.join();
+        for (int k = 0; k < n; ++k) nd->workers[k]->post([&work, k] { work(k); });
+        for (int k = 0; k < n; ++k) nd->workers[k]->wait();
     }
     for (int k = 0; k < n; ++k)
         if (sh[k].rc != TK_OK) { nd->err = "device " + std::to_string(nd->devs[k]) + ": " + sh[k].err; return sh[k].rc; }
@@ -329,9 +404,15 @@ extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uin
     NODE_HIP(nd, hipEventRecord(nd->ev1, rs));
 
     // ---- down to the host ----
-    uint32_t* h_ids = (uint32_t*)tk_pinned_get((total ? total : 1) * 4);
-    uint64_t* h_offs = (uint64_t*)tk_pinned_get((n_docs + 1) * 8);
-    if (!h_ids || !h_offs) { tk_pinned_put(h_ids); tk_pinned_put(h_offs); nd->err = "hipHostMalloc failed"; return TK_ERR_RUNTIME; }
+    *n_ids_res = total;
+    if (ids_dst && total > ids_cap) { nd->err = "ids_out is too small for " + std::to_string(total) + " ids"; return TK_ERR_INVALID_ARG; }
+    uint32_t* h_ids = ids_dst ? ids_dst : (uint32_t*)tk_pinned_get((total ? total : 1) * 4);
+    uint64_t* h_offs = ids_dst ? offs_dst : (uint64_t*)tk_pinned_get((n_docs + 1) * 8);
+    if (!h_ids || !h_offs) {
+        if (!ids_dst) { tk_pinned_put(h_ids); tk_pinned_put(h_offs); }
+        nd->err = "hipHostMalloc failed";
+        return TK_ERR_RUNTIME;
+    }
     hipError_t e = hipSuccess;
     if (total) e = hipMemcpyAsync(h_ids, ids, total * 4, hipMemcpyDeviceToHost, rs);
     if (e == hipSuccess) e = hipMemcpyAsync(h_offs, offs, (n_docs + 1) * 8, hipMemcpyDeviceToHost, rs);
@@ -342,7 +423,7 @@ extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uin
     }
     (void)hipSetDevice(nd->devs[0]);
     if (e != hipSuccess) {
-        tk_pinned_put(h_ids); tk_pinned_put(h_offs);
+        if (!ids_dst) { tk_pinned_put(h_ids); tk_pinned_put(h_offs); }
         nd->err = std::string("gather / result copy failed: ") + hipGetErrorString(e);
         return TK_ERR_RUNTIME;
     }
@@ -354,11 +435,38 @@ extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uin
         if (p > kmax) kmax = p;
     }
     nd->last_kernels_ms = kmax;
+    *ids_res = h_ids;
+    *offs_res = h_offs;
+    return TK_OK;
+}
+
+extern "C" int tk_node_encode_batch(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
+                                    int add_eos, tk_result* out) {
+    if (!nd) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(nd->mu);
+    if (!doc_offsets || !out || (!bytes && doc_offsets[n_docs])) { nd->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    memset(out, 0, sizeof(*out));
+    uint32_t* h_ids = nullptr;
+    uint64_t* h_offs = nullptr;
+    uint64_t total = 0;
+    int rc = node_encode(nd, bytes, doc_offsets, n_docs, add_bos, add_eos, nullptr, 0, nullptr, &h_ids, &h_offs, &total);
+    if (rc != TK_OK) return rc;
     out->ids = h_ids;
     out->offsets = h_offs;
     out->n_ids = total;
     out->n_docs = n_docs;
     return TK_OK;
+}
+
+extern "C" int tk_node_encode_batch_pinned(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_offsets, uint64_t n_docs, int add_bos,
+                                           int add_eos, uint32_t* ids_out, uint64_t ids_capacity, uint64_t* offsets_out, uint64_t* n_ids_out) {
+    if (!nd) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(nd->mu);
+    if (!doc_offsets || !ids_out || !offsets_out || !n_ids_out || (!bytes && doc_offsets[n_docs])) { nd->err = "null argument"; return TK_ERR_INVALID_ARG; }
+    uint32_t* h_ids = nullptr;
+    uint64_t* h_offs = nullptr;
+    *n_ids_out = 0;
+    return node_encode(nd, bytes, doc_offsets, n_docs, add_bos, add_eos, ids_out, ids_capacity, offsets_out, &h_ids, &h_offs, n_ids_out);
 }
 
 extern "C" int tk_node_last_timing(const tk_node* nd, float* kernels_ms_max, float* gather_ms) {

@@ -78,6 +78,13 @@ TK_DEV void wv_lds_sync() {
 }
 TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+TK_DEV void wv_lds_and64(uint64_t* p, uint64_t v) {
+    __hip_atomic_fetch_and(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// workgroup level (tk_long_impl.h: 16 waves merge one long piece): the thread's index in the block, the block barrier
+TK_DEV uint32_t wv_tid() { return threadIdx.x; }
+TK_DEV void wv_block_sync() { __syncthreads(); }
+
 // 16 text bytes at p (any alignment) as 4 little-endian dwords
 TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) {
     typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_u;

@@ -31,6 +31,8 @@ def lib():
         L.emu_flat_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                             u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, u64p, u8p, u8p,
                                             u64p, u64p, ctypes.c_int]
+        L.emu_long_merge.restype = ctypes.c_int64
+        L.emu_long_merge.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, u8p, ctypes.c_uint32, u32p, u64p]
         _LIB = L
     return _LIB
 
@@ -126,3 +128,19 @@ def table_cache_roundtrip(token_bytes, num_special, path):
     if rc != 0:
         raise RuntimeError("emu_table_cache_roundtrip rc=%d: %s" % (rc, lib().emu_last_error().decode()))
     return dict(build_s=float(out[0]), save_s=float(out[1]), load_s=float(out[2]), file_bytes=int(out[3]))
+
+
+def long_merge(token_bytes, num_special, piece, kind):
+    """The round-based workgroup merge of ONE long piece (csrc/tk_long_impl.h) on 16 emulated waves: kind 0 = compacting
+    rounds, 1 = lazy rounds.  Returns the ids (the pure merge: no whole-piece look-up)."""
+    toffs = np.zeros(len(token_bytes) + 1, np.uint32)
+    toffs[1:] = np.cumsum([len(t) for t in token_bytes], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(token_bytes), dtype=np.uint8).copy()
+    data = np.frombuffer(piece, dtype=np.uint8).copy()
+    out = np.zeros(len(piece) + 1, np.uint32)
+    nb = ctypes.c_uint64(0)
+    rc = lib().emu_long_merge(_p(blob, ctypes.c_uint8), _p(toffs, ctypes.c_uint32), len(token_bytes), num_special, int(kind),
+                              _p(data, ctypes.c_uint8), len(piece), _p(out, ctypes.c_uint32), ctypes.byref(nb))
+    if rc < 0:
+        raise RuntimeError("emu_long_merge rc=%d: %s" % (rc, lib().emu_last_error().decode()))
+    return out[:rc].tolist()

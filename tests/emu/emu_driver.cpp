@@ -13,9 +13,11 @@
 #include "../../include/tekken_hip.h"
 #include "../../tekken-rs_amd/csrc/tk_encode_impl.h"
 #include "../../tekken-rs_amd/csrc/tk_flat_impl.h"
+#include "../../tekken-rs_amd/csrc/tk_long_impl.h"
 
 namespace tkemu {
 Wave* g_wave = nullptr;
+Block* g_block = nullptr;
 }
 
 static std::string g_err;
@@ -406,4 +408,41 @@ extern "C" int emu_table_cache_roundtrip(const uint8_t* blob, const uint32_t* of
 extern "C" int emu_table_cache_load(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, const char* path) {
     TkHostTables B;
     return tk_tables_load(B, tk_tables_key(blob, offs, n_ranks, num_special, 1, 2), path) ? TK_OK : TK_ERR_RUNTIME;
+}
+
+
+// The round-based workgroup merges of ONE long piece (tk_long_impl.h) on 16 emulated waves: kind 0 = compacting rounds
+// (tkl_block_merge), 1 = lazy rounds (tks_block_merge).  The scratch (4 n words) and the LDS image sit between guard words
+// (and under ASan between red zones); out_ids must hold n entries; returns the number of ids or a negative code.
+extern "C" int64_t emu_long_merge(const uint8_t* blob, const uint32_t* offs, uint32_t n_ranks, uint32_t num_special, int kind,
+                                  const uint8_t* bytes, uint32_t n, uint32_t* out_ids, uint64_t* n_barriers) {
+    if (n <= 64u || n > TK_LONG_MAX) { g_err = "piece length out of range for the workgroup merges"; return TK_ERR_INVALID_ARG; }
+    TkHostTables T;
+    int rc = tk_build_tables(blob, offs, n_ranks, num_special, 1, 2, T, g_err);
+    if (rc != TK_OK) return rc;
+    const TkTablesView t = T.host_view();
+    const size_t G = 64;
+    std::vector<uint32_t> scratch(G + 4 * (size_t)n + G, 0xDEADBEEFu), out(G + n + G, 0xDEADBEEFu);
+    std::vector<uint8_t> text(bytes, bytes + n);            // (its own allocation: reads past the piece are caught)
+    TksShared* LS = new TksShared();                         // heap: the sanitizer sees its bounds
+    static_assert(sizeof(TklShared) <= sizeof(TksShared), "one LDS image serves both forms");
+    std::vector<uint32_t> result(TKL_WAVES, 0);
+    tkemu::run_block(TKL_WAVES, [&](int lane) {
+        uint32_t r;
+        if (kind == 0) r = tkl_block_merge(t, text.data(), n, scratch.data() + G, out.data() + G, *reinterpret_cast<TklShared*>(LS));
+        else r = tks_block_merge(t, text.data(), n, scratch.data() + G, out.data() + G, *LS);
+        if (lane == 0) result[wv_tid() >> 6] = r;
+    });
+    if (n_barriers) *n_barriers = 0;
+    delete LS;
+    for (size_t i = 0; i < G; ++i)
+        if (scratch[i] != 0xDEADBEEFu || scratch[G + 4 * (size_t)n + i] != 0xDEADBEEFu || out[i] != 0xDEADBEEFu || out[G + n + i] != 0xDEADBEEFu) {
+            g_err = "the workgroup merge wrote outside its scratch / output";
+            return TK_ERR_RUNTIME;
+        }
+    for (int v = 1; v < TKL_WAVES; ++v)
+        if (result[v] != result[0]) { g_err = "the waves disagree on the number of ids"; return TK_ERR_RUNTIME; }
+    if (result[0] > n) { g_err = "more ids than bytes"; return TK_ERR_RUNTIME; }
+    memcpy(out_ids, out.data() + G, sizeof(uint32_t) * result[0]);
+    return (int64_t)result[0];
 }

@@ -26,7 +26,7 @@
 
 namespace tkemu {
 
-enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC, OP_FIRST, OP_ATOMIC, OP_MIN };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_UP1, OP_DN1, OP_SYNC, OP_FIRST, OP_ATOMIC, OP_MIN, OP_BARRIER };
 
 struct Wave {
     ucontext_t sched;
@@ -111,9 +111,104 @@ inline void run_wave(const std::function<void(int)>& body) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// A WORKGROUP of n waves (tk_long_impl.h: 16 waves merge one long piece): every wave is a Wave as above with its own 64
+// fibers; the waves take turns, each running until its lanes park at the next primitive.  A wave whose lanes park at the
+// workgroup barrier (wv_block_sync) waits until every wave of the block is there.  Between two barriers the waves run one
+// after the other, every wave's lanes one after the other: code that is correct on the device -- no cross-wave or
+// cross-lane race between barriers / wave primitives -- computes the same here, and every access goes through the host's
+// sanitizers.  A wave that returns while others wait at a barrier is an error, like on the device.
+// ------------------------------------------------------------------------------------------
+struct Block {
+    std::vector<Wave*> waves;
+    int cur_wave = 0;
+    uint64_t n_barriers = 0;
+};
+extern Block* g_block;   // non-null while run_block executes
+
+inline void run_block(int n_waves, const std::function<void(int)>& body, size_t stack_bytes = 256 * 1024) {
+    static Block* block = nullptr;
+    if (!block) block = new Block();
+    while ((int)block->waves.size() < n_waves) {
+        Wave* w = new Wave();
+        for (int l = 0; l < 64; ++l) w->stacks[l].resize(stack_bytes);
+        block->waves.push_back(w);
+    }
+    Block* b = block;
+    g_block = b;
+    b->n_barriers = 0;
+    std::vector<int> state(n_waves, 0);   // 0 running, 1 at the barrier, 2 done
+    for (int v = 0; v < n_waves; ++v) {
+        Wave* w = b->waves[v];
+        w->body = body;
+        w->n_ops = 0;
+        for (int l = 0; l < 64; ++l) {
+            w->done[l] = false;
+            w->op[l] = OP_NONE;
+            getcontext(&w->ctx[l]);
+            w->ctx[l].uc_stack.ss_sp = w->stacks[l].data();
+            w->ctx[l].uc_stack.ss_size = w->stacks[l].size();
+            w->ctx[l].uc_link = nullptr;
+            makecontext(&w->ctx[l], (void (*)())fiber_entry, 1, l);
+        }
+    }
+    for (;;) {
+        bool any_running = false;
+        for (int v = 0; v < n_waves; ++v) {
+            if (state[v] != 0) continue;
+            any_running = true;
+            Wave* w = b->waves[v];
+            g_wave = w;
+            b->cur_wave = v;
+            int live = 0;
+            for (int l = 0; l < 64; ++l) {
+                if (w->done[l]) continue;
+                w->cur = l;
+                swapcontext(&w->sched, &w->ctx[l]);
+                if (!w->done[l]) ++live;
+            }
+            if (live == 0) { state[v] = 2; continue; }
+            int op = OP_NONE;
+            for (int l = 0; l < 64; ++l) {
+                if (w->done[l]) continue;
+                if (op == OP_NONE) op = w->op[l];
+                else if (op != w->op[l]) {
+                    fprintf(stderr, "tkemu: wave %d: lanes diverged at a primitive (lane %d op %d vs %d)\n", v, l, w->op[l], op);
+                    abort();
+                }
+            }
+            if (live != 64) {
+                fprintf(stderr, "tkemu: wave %d: %d lanes exited early while others wait at op %d\n", v, 64 - live, op);
+                abort();
+            }
+            if (op == OP_BARRIER) { state[v] = 1; continue; }
+            uint64_t bm = 0;
+            for (int l = 0; l < 64; ++l) {
+                w->snap_u32[l] = w->dep_u32[l];
+                if (w->dep_pred[l]) bm |= 1ull << l;
+            }
+            w->snap_ballot = bm;
+            ++w->n_ops;
+        }
+        if (any_running) continue;
+        int at_barrier = 0, done = 0;
+        for (int v = 0; v < n_waves; ++v) { at_barrier += state[v] == 1; done += state[v] == 2; }
+        if (at_barrier == 0) break;
+        if (done != 0) {
+            fprintf(stderr, "tkemu: %d waves returned while %d wait at the workgroup barrier\n", done, at_barrier);
+            abort();
+        }
+        ++b->n_barriers;
+        for (int v = 0; v < n_waves; ++v) state[v] = 0;
+    }
+    g_block = nullptr;
+}
+
 }  // namespace tkemu
 
 TK_DEV int wv_lane() { return tkemu::g_wave->cur; }
+TK_DEV uint32_t wv_tid() { return tkemu::g_block ? (uint32_t)(tkemu::g_block->cur_wave * 64 + tkemu::g_wave->cur) : (uint32_t)tkemu::g_wave->cur; }
+TK_DEV void wv_block_sync() { tkemu::yield_op(tkemu::g_block ? tkemu::OP_BARRIER : tkemu::OP_SYNC); }
 
 TK_DEV uint64_t wv_ballot(bool p) {
     tkemu::Wave* w = tkemu::g_wave;
@@ -218,6 +313,7 @@ TK_DEV uint32_t wv_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 
 TK_DEV void wv_lds_sync() { tkemu::yield_op(tkemu::OP_SYNC); }
 TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+TK_DEV void wv_lds_and64(uint64_t* p, uint64_t v) { *p &= v; }
 
 TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) { memcpy(x, p, 16); }
 TK_DEV void wv_store16(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }

@@ -96,6 +96,16 @@ def test_node_api_single_device_and_rccl_loopback(tk, test_vocab, monkeypatch):
             assert np.array_equal(ids, eids) and np.array_equal(oo, eoo)
         ids, oo = nd.encode_batch(data[:0], offs[:1], True, True)    # no documents
         assert len(ids) == 0 and oo.tolist() == [0]
+        # caller-owned pinned buffers (tk_node_encode_batch_pinned): nothing allocated per call; a buffer that is too small is refused
+        h_data, h_offs = tk.host_empty(len(data), np.uint8), tk.host_empty(len(offs), np.uint64)
+        h_data[:] = data
+        h_offs[:] = offs
+        h_ids, h_oo = tk.host_empty(len(data) + 2 * len(offs), np.uint32), tk.host_empty(len(offs), np.uint64)
+        for _ in range(2):
+            n_ids = nd.encode_batch_into(h_data, h_offs, h_ids, h_oo, True, True)
+            assert n_ids == len(eids) and np.array_equal(h_ids[:n_ids], eids) and np.array_equal(h_oo, eoo)
+        with pytest.raises(tk.TokenizerError):
+            nd.encode_batch_into(h_data, h_offs, h_ids[:100], h_oo, True, True)
         t = nd.last_timing()
         assert t["gather_ms"] >= 0.0
         nd.close()

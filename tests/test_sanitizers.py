@@ -1,7 +1,7 @@
 """Sanitizers where they can run: the CPU build (GPU AddressSanitizer / XNACK runs are not available on the pool).
 
 * `test_device_source_under_asan_ubsan`: tests/emu/libtk_emu_asan.so is the VERY device source (csrc/tk_flat_impl.h,
-  tk_encode_impl.h: every LDS index, queue record, table probe) compiled for the CPU wave emulator with
+  tk_encode_impl.h, tk_long_impl.h: every LDS index, queue record, table probe, and the workgroup merges' scratch) compiled for the CPU wave emulator with
   -fsanitize=address,undefined, and oracle/libtk_oracle_asan.so the oracle; a subset of the emulator / oracle suites is
   re-run against them in a child interpreter (libasan preloaded).  TK_SANITIZE_FULL=1 runs all of test_flat_path.py,
   test_kernel_emu.py, test_oracle_golden.py and test_merge_golden.py that way (seven to ten minutes here; last run clean).
@@ -34,13 +34,15 @@ def test_device_source_under_asan_ubsan():
     env = dict(os.environ, TK_TEST_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     if os.environ.get("TK_SANITIZE_FULL"):
-        sel = ["tests/test_flat_path.py", "tests/test_kernel_emu.py", "tests/test_oracle_golden.py", "tests/test_merge_golden.py"]
+        sel = ["tests/test_flat_path.py", "tests/test_kernel_emu.py", "tests/test_oracle_golden.py", "tests/test_merge_golden.py",
+               "tests/test_long_merge_emu.py"]
         extra = []
     else:
         # the flat chunk kernel + both merge kernels on UTF-8 / run-heavy / dense-piece streams and on the adversarial merge
         # vocabularies; the per-document kernels against the oracle; the oracle against its golden vectors
-        sel = ["tests/test_flat_path.py", "tests/test_kernel_emu.py", "tests/test_oracle_golden.py", "tests/test_merge_golden.py"]
-        extra = ["-k", "test_emu_flat_utf8 or test_emu_flat_runs_and_misses or test_emu_flat_dense_pieces or test_emu_flat_baseline_shapes "
+        sel = ["tests/test_flat_path.py", "tests/test_kernel_emu.py", "tests/test_oracle_golden.py", "tests/test_merge_golden.py",
+               "tests/test_long_merge_emu.py"]
+        extra = ["-k", "test_block_merges or test_emu_cut_decomposition or test_emu_flat_utf8 or test_emu_flat_runs_and_misses or test_emu_flat_dense_pieces or test_emu_flat_baseline_shapes "
                        "or test_emu_flat_handback_and_mixed or test_emu_flat_small_alphabet_packed or test_emu_flat_every_ascii_byte_pair "
                        "or test_emu_long_single_piece or test_emu_split_only or test_emu_small_vocab_known_answer "
                        "or test_emu_reference_vectors_on_consistent_vocab or test_split_matches_independent_engine "

@@ -302,16 +302,31 @@ def main():
         k_ms = float(np.mean(enc_ms))
         achieved = bytes_alg / (k_ms * 1e-3) / 1e9
         traffic, traffic_info = None, {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        # (the PMC passes were taken on the default C2 workload: any other shape or size reports null)
-        is_c2 = args.kind == "ascii" and n_docs == 1_000_000 and args.doc_len == 512 and not distributed
-        if os.path.exists(tpath) and is_c2:
+        # (the PMC passes were taken on three shapes -- C2, C3 and one GPU's share of the Zipf shape, with the default vocabulary --:
+        # any other shape, size or vocabulary reports null)
+        tname = None
+        if not distributed and not args.vocab and args.vocab_fit == "same":
+            if args.kind == "ascii" and n_docs == 1_000_000 and args.doc_len == 512:
+                tname = "hbm_traffic.json"
+            elif args.kind == "mixed" and n_docs == 1_000_000 and args.doc_len == 2048:
+                tname = "hbm_traffic_c3.json"
+            elif args.kind == "zipf" and n_docs == 500_000:
+                tname = "hbm_traffic_zipf.json"
+        tpath = os.path.join(ROOT, "profiles", tname or "none")
+        bound_by = None
+        if tname and os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic = tj.get("tk_flat_kernel_bytes_per_launch")
                 traffic_info = {"traffic_pipeline": tj.get("pipeline_bytes_per_step"), "traffic_measured_at": tj.get("git"),
-                                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, C2)"}
+                                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this shape)" % tname}
+                if tj.get("tk_flat_kernel_valu_floor_ms"):
+                    # the bound that actually applies to the dominant kernel: VALU issue.  floor = VALU wave-instructions per launch
+                    # (SQ_INSTS_VALU, PMC pass at the stamped commit) x 4 clocks / (1 024 SIMDs x 2.4 GHz); frac = floor / measured
+                    bound_by = {"unit": "valu", "insts_per_launch": tj["tk_flat_kernel_valu_insts_per_launch"],
+                                "floor_ms": round(tj["tk_flat_kernel_valu_floor_ms"], 4),
+                                "frac": round(tj["tk_flat_kernel_valu_floor_ms"] / k_ms, 4), "measured_at": tj.get("git")}
             except Exception:  # noqa: BLE001
                 traffic = None
         cfg1, cfgN = CONFIG_OF_KIND[args.kind]
@@ -336,7 +351,8 @@ def main():
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                               "kernel": "tk_flat_kernel", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
                               "pipeline_ms": round(float(np.mean(pipe_ms)), 4),
-                              "pipeline_frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}, **traffic_info),
+                              "pipeline_frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "bound_by": bound_by}, **traffic_info),
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
             "handed_back_docs": eng.last_stats()["handed_back"], "long_piece_records": eng.long_piece_records(), "cut_chunks": eng.cut_chunks(), "host_syncs": eng.last_host_syncs(),
             "node": {"MBps_gather_inclusive": round(value, 1), "MBps_kernels_only": None if kernel_only is None else round(kernel_only, 1),

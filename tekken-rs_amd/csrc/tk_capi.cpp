@@ -502,7 +502,9 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
     a.add_bos = add_bos;
     a.add_eos = add_eos;
     a.t = c->dview;
+#ifdef TK_ABLATE   /* `make ablate` builds only */
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) a.dbg_ablate = atoi(ab);  // timing-only experiments
+#endif
     if (getenv("TK_DEBUG_MARKS")) {
         if (!c->dbg_mark) {
             TK_HIP(c, hipHostMalloc((void**)&c->dbg_mark, 256, hipHostMallocMapped));
@@ -588,7 +590,9 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     fa.wave_first_wide = (uint32_t*)c->f_wfirst.p + wf_narrow;
     fa.t = c->dview;
     fa.pattern = c->pattern;
+#ifdef TK_ABLATE   /* `make ablate` builds only */
     if (const char* ab = getenv("TK_DEBUG_ABLATE")) fa.dbg_ablate = atoi(ab);  // timing-only experiments
+#endif
     // pieces of 65..TKF_LONGCAP bytes stay on the flat path as records (counter 11); TK_FLAT_LONG=0: they hand their documents back
     const uint64_t long_cap = n_bytes / 65 + 1024;
     if (!c->no_flat_long) {

@@ -3,8 +3,8 @@
 //   tk_flat_firstdoc_kernel   per chunk: how many documents start below its loaded region
 //   tk_flat_kernel            split + lookup of one region (64 x TKF_W bytes) per wave, ids chunk-dense
 //   tk_flat_mode1_kernel      the same for tables built with the strong key hash; tk_flat_json_kernel: the split rules of the
-//                             JSON pattern of tekken.json (opt-in); tk_flat_dbg_kernel: timing
-//                             ablations / per-byte split flags compiled in
+//                             JSON pattern of tekken.json (opt-in); tk_flat_split_kernel: the per-byte
+//                             piece-start flags of tk_split_batch compiled in (`make ablate`: the timing ablations too)
 //   tk_merge_kernel           byte-pair merge of the queued pieces (2..16 bytes) that missed the vocabulary, one lane per piece
 //   tk_merge_wide_kernel      the same for pieces of 17..64 bytes (32- and 64-entry LDS columns)
 //   tk_flat_long_kernel       the records of pieces of 65..256 bytes: end of the piece where the chunk did not see it, whole-piece
@@ -26,11 +26,7 @@
 
 #define TKF_BLOCK 256
 #ifndef TKF_OCC
-#if TKF_W == 32
 #define TKF_OCC __attribute__((amdgpu_waves_per_eu(7, 7)))  /* the LDS slices of 28 waves fill the CU: 7 waves per SIMD, <= 72 VGPRs */
-#else
-#define TKF_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))  /* 8 waves per SIMD: <= 64 VGPRs */
-#endif
 #endif
 
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs,
@@ -90,8 +86,8 @@ __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_json_kernel(TkFlatA
     else tk_flat_kernel_body<0, 1, 1>(a, lds_all);
 }
 
-// the same kernels with the timing ablations / per-byte split flags compiled in (TK_DEBUG_ABLATE, tk_split_batch)
-__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_dbg_kernel(TkFlatArgs a) {
+// the same kernels with the per-byte piece-start flags of tk_split_batch compiled in (and, in a `make ablate` build, TK_DEBUG_ABLATE)
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_split_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
     if (a.t.key_hash_mode == 0u) tk_flat_kernel_body<1, 0>(a, lds_all);
     else tk_flat_kernel_body<1, 1>(a, lds_all);
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS_CUT];
     tk_flat_cut_body<0>(a, lds_all);
 }
-__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_dbg_kernel(TkFlatArgs a) {
+__global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_split_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS_CUT];
     tk_flat_cut_body<1>(a, lds_all);
 }
@@ -457,12 +453,12 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     }
     if (blocks > cap) blocks = cap;
     if (a.pattern == 1) hipLaunchKernelGGL(tk_flat_json_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
-    else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_split_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     if (a.cut_list && a.pattern == 0) {
         // the chunks with a piece of more than 64 bytes (none on ordinary text: the blocks read a zero and leave)
-        if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_cut_dbg_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+        if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_cut_split_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
         else hipLaunchKernelGGL(tk_flat_cut_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     }
     return hipGetLastError();

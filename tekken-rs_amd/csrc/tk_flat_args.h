@@ -5,13 +5,11 @@
 
 #include "tk_tables.h"
 
-#ifndef TKF_W
-#define TKF_W 32                                     /* bytes per lane = bits of a lane-layout mask word: 16 or 32 */
-#endif
+#define TKF_W 32                                     /* bytes per lane = bits of a lane-layout mask word */
 #define TKF_REGION (64 * TKF_W)                      /* bytes loaded per chunk: 64 lanes x TKF_W bytes */
 #define TKF_HL 32                                    /* left halo (look-behind context) */
 #define TKF_HR 64                                    /* right halo (look-ahead, ends of the last pieces) */
-#define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* bytes committed per chunk: 928 / 1952 */
+#define TKF_COMMIT (TKF_REGION - TKF_HL - TKF_HR)    /* bytes committed per chunk: 1952 */
 #define TKF_LONGCAP 256u                             /* a piece of 65..LONGCAP bytes keeps its document on the flat path (tk_flat_long_kernel) */
 #define TKF_STRIDE (TKF_COMMIT + 64 + TKF_LONGCAP)   /* id slots per chunk: a piece may reach 63 bytes past the commit range, and the
                                                         chunk's last piece, when its end is not in the region, reserves LONGCAP slots */
@@ -25,11 +23,7 @@
 #define TKF_MISSOFF3 (TKF_MISSOFF2 + (TKF_OWN + 16u) / 17u)
 #define TKF_MISSCAP ((TKF_MISSOFF3 + (TKF_OWN + 32u) / 33u + 7u) & ~7u)
 /* queue record: position in the region | length << POSBITS | id slot << (POSBITS + 7) */
-#if TKF_W == 32
 #define TKF_POSBITS 11
-#else
-#define TKF_POSBITS 10
-#endif
 #define TKF_REC(pos, len, slot) ((pos) | ((len) << TKF_POSBITS) | ((slot) << (TKF_POSBITS + 7)))
 #define TKF_REC_POS(rec) ((rec) & ((1u << TKF_POSBITS) - 1u))
 #define TKF_REC_LEN(rec) (((rec) >> TKF_POSBITS) & 127u)

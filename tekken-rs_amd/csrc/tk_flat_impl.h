@@ -36,23 +36,13 @@
 #include "tk_encode_impl.h"
 #include "tk_flat_args.h"
 
-#if TKF_W == 32
 #define TKF_WM 0xFFFFFFFFu
 #define TKF_LOGW 5
 #define TKF_TOPBIT 0x80000000u
-#else
-#define TKF_WM 0xFFFFu
-#define TKF_LOGW 4
-#define TKF_TOPBIT 0x8000u
-#endif
 #define TKF_NHL (TKF_HL / TKF_W)                     /* lanes of the left halo: 2 / 1 */
 /* entries of the LDS piece list.  16 bytes per lane: every byte could start a piece.  32 bytes per lane: a chunk with
    more pieces than this (an average of under two bytes per piece over 2 KB) is handed back as a whole */
-#if TKF_W == 32
 #define TKF_LISTCAP 1056
-#else
-#define TKF_LISTCAP (TKF_REGION + 8)
-#endif
 #define TKF_MAXPIECES (TKF_LISTCAP - 2)              /* + the sentinel */
 
 // LDS words of one wave
@@ -80,14 +70,9 @@
 // ------------------------------------------------------------------------------------------
 // (own word above / below the neighbour's in one register, then ONE bit-field extract: 3 VALU per shift, and the
 // combined word is shared by shifts of the same mask)
-#if TKF_W == 32
 // (one funnel shift over {own word : neighbour's word}: DPP move + v_alignbit)
 TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return (uint32_t)((((uint64_t)x << 32) | (uint64_t)wv_dn1(x)) >> (32 - k)); }  // 1 <= k <= 31
 TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return (uint32_t)((((uint64_t)wv_up1(x) << 32) | (uint64_t)x) >> k); }
-#else
-TK_DEV uint32_t tkf_shl(uint32_t x, int k) { return (((x << TKF_W) | wv_dn1(x)) >> (TKF_W - k)) & TKF_WM; }  // 1 <= k <= 16
-TK_DEV uint32_t tkf_shr(uint32_t x, int k) { return (((wv_up1(x) << TKF_W) | x) >> k) & TKF_WM; }
-#endif
 TK_DEV uint32_t tkf_shl_any(uint32_t x, int k, int lane) {
     const int q = k >> TKF_LOGW, r = k & (TKF_W - 1);
     const int s1 = lane - q, s2 = lane - q - 1;
@@ -110,11 +95,7 @@ TK_DEV bool tkf_any(uint32_t x) { return wv_ballot(x != 0u) != 0ull; }
 // (G = lanes that generate a carry, P = lanes that would pass one on) hands every lane its carry-in
 TK_DEV uint32_t tkf_add(uint32_t a, uint32_t b) {
     const uint32_t t = a + b;
-#if TKF_W == 32
     const uint64_t G = wv_ballot(t < a);                  // the word itself overflowed
-#else
-    const uint64_t G = wv_ballot((t >> TKF_W) != 0u);
-#endif
     const uint64_t P = wv_ballot((t & TKF_WM) == TKF_WM);
     const uint64_t x = G | P;
     const uint64_t cin = (x + G) ^ x ^ G;  // carry into lane l = bit l
@@ -164,7 +145,6 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     uint32_t a_lo = x[0], a_hi = x[1], b_lo = x[2], b_hi = x[3];
     tkf_transpose8(a_lo, a_hi);
     tkf_transpose8(b_lo, b_hi);
-#if TKF_W == 32
     // four groups of 8 bytes: plane p = byte p of the four transposed groups -- a 4 x 4 byte transpose (v_perm), twice
     uint32_t c_lo = x[4], c_hi = x[5], d_lo = x[6], d_hi = x[7];
     tkf_transpose8(c_lo, c_hi);
@@ -177,12 +157,6 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     const uint32_t v2 = wv_perm(d_hi, c_hi, 0x05010400u), v3 = wv_perm(d_hi, c_hi, 0x07030602u);
     const uint32_t p4 = wv_perm(v2, u2, 0x05040100u), p5 = wv_perm(v2, u2, 0x07060302u);
     const uint32_t p6 = wv_perm(v3, u3, 0x05040100u), p7 = wv_perm(v3, u3, 0x07060302u);
-#else
-    const uint32_t p0 = wv_perm(b_lo, a_lo, 0x07030400u) & 0xFFFFu, p1 = wv_perm(b_lo, a_lo, 0x07030501u) & 0xFFFFu;
-    const uint32_t p2 = wv_perm(b_lo, a_lo, 0x07030602u) & 0xFFFFu, p3 = wv_perm(b_lo, a_lo, 0x07030703u) & 0xFFFFu;
-    const uint32_t p4 = wv_perm(b_hi, a_hi, 0x07030400u) & 0xFFFFu, p5 = wv_perm(b_hi, a_hi, 0x07030501u) & 0xFFFFu;
-    const uint32_t p6 = wv_perm(b_hi, a_hi, 0x07030602u) & 0xFFFFu, p7 = wv_perm(b_hi, a_hi, 0x07030703u) & 0xFFFFu;
-#endif
     TkfClass c;
     const uint32_t hz = TKF_WM & ~(p7 | p6 | p5 | p4);            // high nibble 0
     const uint32_t pre = p6 & ~p7;                                // 0x40..0x7F: letters differ in bit 5 only
@@ -440,14 +414,22 @@ TK_DEV void tk_flat_init_lds(const TkFlatArgs& a, uint32_t* lds, int lane) {
 
 TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
-// DBG = 0: the production instantiation.  DBG = 1 adds the timing ablations (TK_DEBUG_ABLATE) and the per-byte piece-start
-// flags of tk_split_batch: every one of those tests costs scalar registers and VALU slots the kernel does not have.
+// DBG = 0: the production instantiation.  DBG = 1 adds the per-byte piece-start flags of tk_split_batch (and, in a `make ablate`
+// build, the timing ablations of TK_DEBUG_ABLATE): every one of those tests costs scalar registers and VALU slots the kernel does not have.
 // MODE = the key hash the tables were built with (TkTablesView::key_hash_mode), a compile-time constant here.
 // PAT = 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in).
 // CUT = 0: the production instantiation; a chunk that holds a piece of more than 64 bytes (two neighbouring lanes without a
 // piece start) is appended to a.cut_list and left untouched -- the function returns true.  CUT = 1 (tk_flat_cut_kernel, over
 // that list): the same chunk work, and pieces of more than 64 bytes are cut into FRAGMENTS wherever the vocabulary rules out a
 // part that spans the boundary (step 4b); fragments merge on their own, without the whole-piece look-up.
+// timing-only ablations of the flat kernel (TK_DEBUG_ABLATE): compiled in by `make ablate` (-DTK_ABLATE) only -- the shipped
+// library's DBG instantiation carries nothing but the per-byte piece-start flags of tk_split_batch
+#ifdef TK_ABLATE
+#define TKF_ABL(a, bit) (DBG && ((a).dbg_ablate & (bit)))
+#else
+#define TKF_ABL(a, bit) false
+#endif
+
 template <int DBG, int MODE, int PAT = 0, int CUT = 0>
 TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
@@ -578,7 +560,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             m.M = cl[320 + lane];
         }
     }
-    if (DBG && (a.dbg_ablate & 16)) {
+    if (TKF_ABL(a, 16)) {
         // (keeps the work alive without producing slot counts: the downstream kernels must see an empty chunk)
         const uint32_t v = m.L + m.N + m.S + m.NL + m.SP + m.AP + m.HI + m.STMD + m.RV + m.E + m.LL;
         if (lane == 0) {
@@ -613,7 +595,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     // ---- 3. piece starts ---------------------------------------------------------------------------
     uint32_t SPR, cont;
     uint32_t PS = PAT ? tkf_rules_json(m, DS, lane, &SPR, &cont) : tkf_rules(m, DS, lane, &SPR, &cont);
-    if (DBG && (a.dbg_ablate & 8)) {
+    if (TKF_ABL(a, 8)) {
         if (lane == 0) {
             a.kcount[c] = (PS + SPR + cont) == 0xFFFFFFFFu ? 1u : 0u;
             for (int k = 0; k < 4; ++k) a.miss_count[k * a.n_chunks + c] = 0u;
@@ -626,7 +608,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // instantiation.  Both chunks of a piece that crosses a commit boundary decide alike: the one it starts in sees no
         // start in its right halo (lanes 62, 63), the next one none in its first 64 commit bytes (lanes 2, 3).
         const uint64_t Zm = wv_ballot(PS == 0u) & ~(((uint64_t)1 << TKF_NHL) - 1ull);
-        if (TKF_W == 32 && (Zm & (Zm >> 1))) {
+        if (Zm & (Zm >> 1)) {
             const uint64_t lc = (uint64_t)wv_first(lds[TKF_L_CONST + 6]) | ((uint64_t)wv_first(lds[TKF_L_CONST + 7]) << 32);
             if (lc != 0ull) {
                 const uint32_t* ctl = reinterpret_cast<const uint32_t*>(wv_global_ptr(lc));
@@ -655,18 +637,10 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     {
         // (A) a digit / CR-LF run that comes from below the region and covers the whole left halo
         // (the region may begin inside a code point: its leading continuation bytes have no class and count as part of the run)
-#if TKF_NHL == 2
-        const uint32_t d0 = wv_readlane(DS, 0) | wv_readlane(DS, 1);
-        const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0), n1 = wv_readlane(m.N, 1);
-        const uint32_t tailc = PAT ? (m.NL | m.SL) : m.NL;   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
-        const uint32_t l0 = wv_readlane(tailc, 0), l1 = wv_readlane(tailc, 1);
-        const bool covered = (n0 == TKF_WM && n1 == TKF_WM) || (l0 == TKF_WM && l1 == TKF_WM);
-#else
         const uint32_t d0 = wv_readlane(DS, 0);
         const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0);
         const uint32_t l0 = wv_readlane(PAT ? (m.NL | m.SL) : m.NL, 0);   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
         const bool covered = n0 == TKF_WM || l0 == TKF_WM;
-#endif
         if (r0 > 0 && d0 == 0u && covered && lane == TKF_NHL) BAD |= 1u;
         if (PAT) {
             // JSON pattern: two more runs whose state comes from below the region -- a word run (upper or lower side?) and a
@@ -674,10 +648,6 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             const uint32_t lead_cont = m.U8C & ~(m.U8C + 1u);
             const uint32_t wd = m.L | m.X | m.M, om = (TKF_WM & ~(m.L | m.X | m.N | m.S));
             bool cov2 = wv_readlane(wd | lead_cont, 0) == TKF_WM || wv_readlane(om | lead_cont, 0) == TKF_WM;
-#if TKF_NHL == 2
-            cov2 = (wv_readlane(wd | lead_cont, 0) == TKF_WM && wv_readlane(wd, 1) == TKF_WM) ||
-                   (wv_readlane(om | lead_cont, 0) == TKF_WM && wv_readlane(om, 1) == TKF_WM);
-#endif
             if (r0 > 0 && d0 == 0u && cov2 && lane == TKF_NHL) BAD |= 1u;
         }
         // (B) a white-space run that reaches the region end, goes on in the same document and started inside
@@ -789,7 +759,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         pfx_all = pf & 0xFFFFu; pfx_own = pf >> 16;
         np_all = tot & 0xFFFFu; np_own = tot >> 16;
     }
-    const int npass = (TKF_W == 32 && np_all > TKF_MAXPIECES) ? 2 : 1;
+    const int npass = np_all > TKF_MAXPIECES ? 2 : 1;
     uint32_t* tmp = a.tmp + c * TKF_STRIDE;
     uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
     uint32_t E = 0;                                         // slots beyond one per piece so far
@@ -890,13 +860,13 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             kk[2] = wv_alignbyte(t3, t2, sh) & km[2]; kk[3] = wv_alignbyte(t4, t3, sh) & km[3];
         }
         uint32_t r = kk[0];                                 // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
-        if (DBG && (a.dbg_ablate & 1)) {
+        if (TKF_ABL(a, 1)) {
             r = 7u;
-        } else if (DBG && (a.dbg_ablate & 64)) {
+        } else if (TKF_ABL(a, 64)) {
             r = (kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) & 0xFFFFu;                                            // timing: no hash, no table
         } else {
             const uint32_t h = tk_key_hash((uint32_t)MODE, kk[0], kk[1], kk[2], kk[3], len);
-            if (DBG && (a.dbg_ablate & 128)) {
+            if (TKF_ABL(a, 128)) {
                 r = h & 0xFFFFu;                                                                      // timing: no table
             } else if (len - 2u <= 14u) {                   // 2..16 bytes: exact-key probe
                 const uint32_t* kc = lds + TKF_L_CONST;
@@ -927,7 +897,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 const bool have_ctl = (lds[TKF_L_CONST + 6] | lds[TKF_L_CONST + 7]) != 0u;
                 if (!PAT && have_ctl && (lopen || len <= TKF_LONGCAP) && !(CUT && frag && lopen)) lres = lopen ? TKF_LONGCAP : len;
                 else toolong = true;                        // (a fragment whose end the region does not show: no cut in 64 bytes)
-            } else if (len > 16u && !(DBG && (a.dbg_ablate & 1)) && !(CUT && frag)) {
+            } else if (len > 16u && !TKF_ABL(a, 1) && !(CUT && frag)) {
                 // 17..64 bytes: KEY64, the piece's dwords from the LDS copy of the region (the polynomial byte hash of LONG,
                 // two multiplies and a global load per byte, was 44 % of this kernel on mixed UTF-8 text, whose words are long)
                 r = tk_probe_key64(t, lds + TKF_L_TXT + (pos >> 2), pos & 3u, len);
@@ -937,7 +907,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 // A batch with a long piece is finished HERE, in the general forms of the bookkeeping below, so that the
                 // common path carries nothing of it (two more spilled scalars there were 1.5 % of the kernel on C2).
                 const bool longp = lres != 0u;
-                const bool lmiss = r == TK_RANK_MAX && !toolong && !longp && !(DBG && (a.dbg_ablate & 2));
+                const bool lmiss = r == TK_RANK_MAX && !toolong && !longp && !TKF_ABL(a, 2);
                 uint32_t lslot = base_own + idx + E;
                 {
                     uint32_t tot;
@@ -981,13 +951,13 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 wv_lds_sync();                              // positions read before they are overwritten
                 if (act) {
                     list[idx] = (uint16_t)lslot;
-                    if (!lmiss && !longp && !(DBG && (a.dbg_ablate & 4))) tmp[lslot] = r + t.num_special;
+                    if (!lmiss && !longp && !TKF_ABL(a, 4)) tmp[lslot] = r + t.num_special;
                 }
                 continue;
             }
         }
         // (a lane without a piece holds a byte value in r: never TK_RANK_MAX)
-        const bool miss = r == TK_RANK_MAX && !toolong && !(DBG && (a.dbg_ablate & 2));
+        const bool miss = r == TK_RANK_MAX && !toolong && !TKF_ABL(a, 2);
         uint32_t slot = base_own + idx + E;
         const uint64_t MB = wv_ballot(miss);
         if (MB) {
@@ -1028,7 +998,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         wv_lds_sync();                                      // positions read before they are overwritten
         if (act) {
             list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
-            if (!miss && !(DBG && (a.dbg_ablate & 4))) tmp[slot] = r + t.num_special;
+            if (!miss && !TKF_ABL(a, 4)) tmp[slot] = r + t.num_special;
         }
     }
     if (pass + 1 < npass) {

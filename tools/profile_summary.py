@@ -67,21 +67,41 @@ def main():
     if os.path.exists(cj):
         with open(cj) as f, open(os.path.join(out, "%s_cjk_probe.txt" % tag), "w") as g:
             g.writelines(l for l in f if l.startswith("runs of"))
+    benches = {}
+    for cfg in ("c2", "c3", "zipf"):
+        bp = os.path.join(out, "%s_bench_%s.json" % (tag, cfg))
+        if os.path.exists(bp):
+            with open(bp) as f:
+                benches[cfg] = json.loads(f.readline())
+    # one traffic / counter summary per shape the PMC passes were taken on (tools/pmc_flat.sh <tag> [<suffix> <shape>])
+    for sfx, cfg, tname in (("", "c2", "hbm_traffic.json"), ("_c3", "c3", "hbm_traffic_c3.json"), ("_zipf", "zipf", "hbm_traffic_zipf.json")):
+        summarize(tag, sfx, benches.get(cfg), os.path.join(out, tname), os.path.join(out, "%s_sq_counters%s.json" % (tag, sfx)), go)
+
+
+KERNELS_ALL = KERNELS + ("tk_flat_cut_kernel", "tk_flat_todo_kernel", "tk_flat_long_kernel", "tk_flat_long128_kernel", "tk_flat_long_coop_kernel",
+                         "tk_encode_kernel<3>", "tk_long_walk_kernel", "tk_long_merge_kernel", "tk_long_compact_kernel")
+
+
+def summarize(tag, sfx, bench, tpath, sqpath, go):
+    dirs = [d for d in sorted(glob.glob(os.path.join(go, "pmc_%s%s_*" % (tag, sfx)))) if os.path.isdir(d)]
+    if sfx == "":
+        dirs = [d for d in dirs if os.path.basename(d).count("_") == 2]      # pmc_<tag>_<group> only, not the suffixed shapes
+    if not dirs:
+        return
     n_docs = bench["config"]["docs_total"] if bench else 1_000_000
     n_ids = bench["config"]["ids_total"] if bench else 98_128_307
     allc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in sorted(glob.glob(os.path.join(go, "pmc_%s_*" % tag))):
-        if not os.path.isdir(d):
-            continue
+    for d in dirs:
         for k, cs in counters(os.path.join(d, "%s_counter_collection.csv" % tag)).items():
+            k = k.replace("void ", "")
             for cname, v in cs.items():
                 allc[k][cname].extend(v)
     mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in allc.items()}
     git = (bench or {}).get("build", {}).get("git")
-    res = {"round": tag, "git": git,
-           "command": "tools/pmc_flat.sh: one rocprofv3 --pmc <group> --kernel-trace --output-format csv pass per counter group over "
-                      "python3 bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0",
-           "raw_per_launch_KB": {k: {c: mean[k][c] for c in ("FETCH_SIZE", "WRITE_SIZE") if c in mean.get(k, {})} for k in KERNELS}}
+    res = {"round": tag, "git": git, "shape": (bench or {}).get("config", {}).get("workload"),
+           "command": "tools/pmc_flat.sh %s %s...: one rocprofv3 --pmc <group> --kernel-trace --output-format csv pass per counter group over "
+                      "python3 bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 <shape>" % (tag, sfx),
+           "raw_per_launch_KB": {k: {c: mean[k][c] for c in ("FETCH_SIZE", "WRITE_SIZE") if c in mean.get(k, {})} for k in KERNELS_ALL if k in mean}}
     # FETCH_SIZE calibration (MI355X_MICROARCH.md: exact 1/2 for 16-B/lane streams, other widths must be calibrated on a
     # known byte count): the assembly kernel reads a known number of bytes with 4-B/lane loads
     asm = mean.get("tk_flat_assemble_kernel", {})
@@ -105,7 +125,7 @@ def main():
     # the whole pipeline of one step: every tokenization kernel, reads at FETCH_SIZE x 2 (the upper bound: exact for the
     # 16-B/lane streams, too high for scattered probes and 4-B/lane loads), writes as counted
     per_kernel = {}
-    for k in KERNELS:
+    for k in KERNELS_ALL:
         m = mean.get(k, {})
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             launches_per_step = {"tk_scan_block_sums": 2, "tk_scan_top": 2, "tk_scan_apply": 2}.get(k, 1)
@@ -115,11 +135,15 @@ def main():
         res["pipeline_bytes_per_step"] = sum(v["read_upper"] + v["write"] for v in per_kernel.values())
         if bench:
             res["pipeline_traffic_over_algorithmic"] = res["pipeline_bytes_per_step"] / bench["roofline"]["bytes_alg_per_launch"]
-    with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
+    # the arithmetic floor of the dominant kernel: VALU wave-instructions x 4 clocks over 1 024 SIMDs at 2.4 GHz
+    if "SQ_INSTS_VALU" in fk:
+        res["tk_flat_kernel_valu_insts_per_launch"] = fk["SQ_INSTS_VALU"]
+        res["tk_flat_kernel_valu_floor_ms"] = fk["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.4e9 * 1e3
+    with open(tpath, "w") as f:
         json.dump(res, f, indent=1)
     sq = {k: {c: v for c, v in mean.get(k, {}).items() if c not in ("FETCH_SIZE", "WRITE_SIZE")} for k in KERNELS[:4]}
-    with open(os.path.join(out, "%s_sq_counters.json" % tag), "w") as f:
-        json.dump({"git": git, "per_launch": sq, "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}, f, indent=1)
+    with open(sqpath, "w") as f:
+        json.dump({"git": git, "shape": res["shape"], "per_launch": sq, "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)"}, f, indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "raw_per_launch_KB"}, indent=1))
 
 

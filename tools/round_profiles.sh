@@ -1,22 +1,22 @@
 #!/bin/bash
-# Everything the round's profiles/ needs, on the GPU box:  tools/round_profiles.sh r02
-# (bench lines for every BASELINE shape, kernel trace + stats, PMC passes; tools/profile_summary.py <tag> turns
-# gpurun_out/ into the committed files under profiles/)
-tag=${1:-r02}
+# Everything the round's profiles/ needs, on the GPU box:  tools/round_profiles.sh r03
+# (bench lines for every BASELINE shape, kernel traces + stats, one-step timelines, PMC passes per shape;
+# tools/profile_summary.py <tag> turns gpurun_out/ into the committed files under profiles/)
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
 Q="--decode-steps 0 --host-steps 0 --single-docs 0"
 timeout -k 10 300 python bench.py > $out/bench_${tag}_c2.json 2> $out/bench_${tag}_c2.err || exit 1
 echo "c2 done"
+timeout -k 10 300 python bench.py --vocab-fit heldout --steps 100 --cpu-passes 1 --cpu-sample-docs 100000 --cpu-threads 1 $Q > $out/bench_${tag}_c2_heldout.json 2> $out/bench_${tag}_c2_heldout.err || exit 1
+echo "c2 (held-out vocabulary) done"
 timeout -k 10 300 python bench.py --kind mixed --doc-len 2048 --docs 1000000 --steps 10 --warmup 2 --cpu-passes 1 --cpu-sample-docs 20000 --decode-steps 3 --host-steps 0 --single-docs 0 > $out/bench_${tag}_c3.json 2> $out/bench_${tag}_c3.err || exit 1
 echo "c3 done"
-if [ -f assets/synth_tekken_mixed50k.json ]; then
-  timeout -k 10 300 python bench.py --vocab assets/synth_tekken_mixed50k.json --kind mixed --doc-len 2048 --docs 1000000 --steps 10 --warmup 2 --cpu-passes 1 --cpu-sample-docs 20000 $Q > $out/bench_${tag}_c3_vocab50k.json 2> $out/bench_${tag}_c3_vocab50k.err || exit 1
-  echo "c3 (vocabulary trained on 50 k mixed documents) done"
-fi
 timeout -k 10 300 python bench.py --kind zipf --docs 500000 --steps 10 --warmup 2 --cpu-passes 1 --cpu-sample-docs 50000 $Q > $out/bench_${tag}_zipf.json 2> $out/bench_${tag}_zipf.err || exit 1
 echo "zipf (500 k documents = one GPU's share of BASELINE configs[4]) done"
+TK_TAIL=serial timeout -k 10 300 python bench.py --kind zipf --docs 500000 --steps 10 --warmup 2 --cpu-passes 0 $Q > $out/bench_${tag}_zipf_serial_tail.json 2> $out/bench_${tag}_zipf_serial_tail.err || exit 1
+echo "zipf with the tail behind the merge kernels (TK_TAIL=serial: the A / B of the second stream) done"
 timeout -k 10 600 python bench.py --kind zipf --docs 4000000 --steps 5 --warmup 1 --cpu-passes 1 --cpu-sample-docs 50000 $Q > $out/bench_${tag}_zipf4m.json 2> $out/bench_${tag}_zipf4m.err || exit 1
 echo "zipf (4 M documents = all of configs[4] on one GPU) done"
 timeout -k 10 200 python tools/load_time.py > $out/load_time_${tag}.json 2> $out/load_time_${tag}.err || exit 1
@@ -25,5 +25,13 @@ timeout -k 10 200 python tools/gpu_longpiece_time.py > $out/longpiece_time_${tag
 echo "long piece timing done"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag} -o ${tag} -- python3 $root/bench.py --steps 20 --warmup 2 --cpu-passes 0 --host-steps 0 --single-docs 0 > $out/prof_${tag}.log 2>&1 || exit 1
-echo "kernel trace done"
-cd $root && tools/pmc_flat.sh ${tag}
+echo "kernel trace (c2) done"
+cd $root
+bash tools/trace_step.sh ${tag}_c3 --kind mixed --doc-len 2048 --docs 1000000 --steps 3 --warmup 1 > /dev/null || exit 1
+echo "kernel trace + timeline (c3) done"
+bash tools/trace_step.sh ${tag}_zipf --kind zipf --docs 500000 --steps 3 --warmup 1 > /dev/null || exit 1
+echo "kernel trace + timeline (zipf) done"
+tools/pmc_flat.sh ${tag} "" || exit 1
+tools/pmc_flat.sh ${tag} _c3 --kind mixed --doc-len 2048 --docs 1000000 || exit 1
+tools/pmc_flat.sh ${tag} _zipf --kind zipf --docs 500000 || exit 1
+echo "all done"

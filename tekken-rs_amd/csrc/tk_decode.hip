@@ -244,14 +244,15 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     }
 }
 
-// One wave per document, 64 bytes per step, one lane per byte: the same checks as tk_validate_kernel (RFC 3629) with the
-// extra rule that positions flagged in run_bits cut sequences.  Everything a byte needs to know about its neighbours comes
-// from the wave (DPP shifts of the loaded bytes, ballots of the lead / continuation classes, the step's 64 boundary bits from
-// three uniform loads): a LEAD byte checks the bytes it claims, a continuation byte only that some lead claimed it.  A step
-// advances 58 bytes: leads are judged in lanes 0..60 (their up to three continuation bytes are in the window), continuation
-// bytes in lanes 3..60 (every lead that could claim them is a judged lane of the window) -- from lane 0 in the first step of
-// a document; the lanes 58..63 of a step are the lanes 0..5 of the next one.
-// (The first form let every byte >= 0x80 look around with its own global loads: 16 of the 21 ms of a C3 decode.)
+// One wave per document, FOUR BYTES PER LANE: 256 bytes per step, one aligned dword per lane (the same checks as
+// tk_validate_kernel -- RFC 3629 -- with the extra rule that positions flagged in run_bits cut sequences).  A lane judges the
+// four bytes of its dword inside a twelve-byte window {previous lane's dword, its own, the next lane's}: a LEAD byte checks the
+// bytes it claims (count, ranges, no run start inside the sequence, all of it inside the document), a CONTINUATION byte only
+// that some lead in the three bytes before it claims it (that lead's own check settles the rest).  The neighbour dwords come from
+// DPP shifts; lane 0's left neighbour is the last dword of the step before (a scalar carried along), lane 63's right neighbour
+// lane 0 of the step after (loaded one step ahead with the rest).  The run-start bits of the window come from two words of
+// run_bits per lane.  Bytes outside the document read as NUL, which claims nothing and needs nothing.
+// (Round 2's form took one lane per byte, 58 bytes per step at about a hundred instructions: 5.8 of the 10.7 ms of a C3 decode.)
 __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
@@ -260,56 +261,76 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
     for (uint64_t d = wave; d < a.n_docs; d += n_waves) {
         if (a.doc_hi[d] == 0u) continue;            // the emit kernel saw only ASCII bytes: always valid
         const uint64_t s0 = a.out_offs[d], s1 = a.out_offs[d + 1];
+        if (s1 == s0) continue;
         bool err = false;
-        // (the loads of a step are issued one step ahead: a step is short, and its one round trip was all a wave waited for)
-        uint32_t nb0 = s0 + (uint64_t)lane < s1 ? (uint32_t)b[s0 + lane] : 0u;
-        uint32_t nw0 = a.run_bits[s0 >> 5], nw1 = a.run_bits[(s0 >> 5) + 1], nw2 = a.run_bits[(s0 >> 5) + 2];
-        for (uint64_t p0 = s0; p0 < s1; p0 += 58) {
-            const uint64_t p = p0 + (uint64_t)lane;
-            const bool in = p < s1;
-            const uint32_t b0 = nb0;                                // (past the end: ASCII NUL, which claims nothing and needs nothing)
-            // (the same three words in every lane: on the scalar unit from here)
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw0), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw1),
-                           w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw2);
-            {
-                const uint64_t q0 = p0 + 58;
-                if (q0 < s1) {
-                    nb0 = q0 + (uint64_t)lane < s1 ? (uint32_t)b[q0 + lane] : 0u;
-                    nw0 = a.run_bits[q0 >> 5]; nw1 = a.run_bits[(q0 >> 5) + 1]; nw2 = a.run_bits[(q0 >> 5) + 2];
+        const uint64_t A0 = s0 & ~3ull;
+        // the dword at q, bytes outside [s0, s1) as NUL (out_bytes is allocated in whole dwords)
+        auto load = [&](uint64_t q) -> uint32_t {
+            if (q >= s1 || q + 4 <= s0) return 0u;
+            uint32_t w = *reinterpret_cast<const uint32_t*>(b + q);
+            if (q < s0) w &= 0xFFFFFFFFu << (8u * (uint32_t)(s0 - q));
+            if (q + 4 > s1) w &= 0xFFFFFFFFu >> (8u * (uint32_t)(q + 4 - s1));
+            return w;
+        };
+        uint32_t nw = load(A0 + 4ull * (uint64_t)lane);
+        uint32_t carry = 0u;                        // the dword in front of the step's first one (in front of the document: NUL)
+        for (uint64_t p0 = A0; p0 < s1; p0 += 256) {
+            const uint64_t q = p0 + 4ull * (uint64_t)lane;
+            const uint32_t w = nw;
+            nw = load(q + 256);
+            const uint32_t first_next = (uint32_t)__builtin_amdgcn_readlane((int)nw, 0);
+            uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1: lane l <- lane l - 1
+            uint32_t xw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false);   // wave_shl:1: lane l <- lane l + 1
+            if (lane == 0) pw = carry;
+            if (lane == 63) xw = first_next;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+            if (__builtin_amdgcn_ballot_w64((w & 0x80808080u) != 0u) == 0ull) continue;               // an ASCII step (wave-uniform)
+            if ((w & 0x80808080u) != 0u && q < s1) {
+                // run-start bits of the positions q - 4 .. q + 27 (bit k: a run starts at q - 4 + k)
+                uint32_t RB;
+                if (q >= 4) {
+                    const uint64_t rb = q - 4;
+                    const uint32_t r0 = a.run_bits[rb >> 5], r1 = a.run_bits[(rb >> 5) + 1];
+                    const uint32_t sh = (uint32_t)(rb & 31u);
+                    RB = sh ? ((r0 >> sh) | (r1 << (32u - sh))) : r0;
+                } else {
+                    RB = a.run_bits[0] << 4;
+                }
+                const uint64_t fwd = (uint64_t)w | ((uint64_t)xw << 32);    // bytes q .. q + 7
+                const uint64_t back = (uint64_t)pw | ((uint64_t)w << 32);   // bytes q - 4 .. q + 3
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint64_t p = q + k;
+                    const uint32_t b0 = (uint32_t)(fwd >> (8u * k)) & 0xFFu;
+                    if (b0 < 0x80u || p < s0 || p >= s1) continue;
+                    if (b0 >= 0xC0u) {
+                        const uint32_t b1 = (uint32_t)(fwd >> (8u * k + 8u)) & 0xFFu, b2 = (uint32_t)(fwd >> (8u * k + 16u)) & 0xFFu,
+                                       b3 = (uint32_t)(fwd >> (8u * k + 24u)) & 0xFFu;
+                        const uint32_t need = b0 >= 0xF8u ? 99u : b0 >= 0xF0u ? 3u : b0 >= 0xE0u ? 2u : b0 >= 0xC2u ? 1u : 99u;
+                        bool ok = need != 99u && p + need < s1;
+                        if (ok) {
+                            const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
+                            ok = c1 && (need < 2u || c2) && (need < 3u || c3);
+                            if ((RB >> (4u + k + 1u)) & ((1u << need) - 1u)) ok = false;     // a run starts inside the sequence
+                            if (b0 == 0xE0u && b1 < 0xA0u) ok = false;   // overlong 3-byte
+                            if (b0 == 0xEDu && b1 >= 0xA0u) ok = false;  // surrogates
+                            if (b0 == 0xF0u && b1 < 0x90u) ok = false;   // overlong 4-byte
+                            if (b0 == 0xF4u && b1 >= 0x90u) ok = false;  // > U+10FFFF
+                            if (b0 > 0xF4u) ok = false;
+                        }
+                        if (!ok) err = true;
+                    } else {
+                        // a continuation byte: claimed by a lead one, two or three bytes back, nothing but continuation bytes and
+                        // no run start in between (a run that starts AT p cuts as well)
+                        const uint32_t m1 = (uint32_t)(back >> (8u * k + 24u)) & 0xFFu, m2 = (uint32_t)(back >> (8u * k + 16u)) & 0xFFu,
+                                       m3 = (uint32_t)(back >> (8u * k + 8u)) & 0xFFu;
+                        const uint32_t rb = RB >> (4u + k - 2u);             // bit 0: p - 2, bit 1: p - 1, bit 2: p
+                        const bool k1 = (m1 & 0xC0u) == 0x80u, k2 = (m2 & 0xC0u) == 0x80u;
+                        const bool cl = (m1 >= 0xC0u && !(rb & 4u)) || (k1 && m2 >= 0xE0u && !(rb & 6u)) || (k1 && k2 && m3 >= 0xF0u && !(rb & 7u));
+                        if (!cl) err = true;
+                    }
                 }
             }
-            // the bytes at p + 1 .. p + 3 (lanes past the window end read 0: such a lead is judged in the next step)
-            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0x130, 0xF, 0xF, false);   // wave_shl:1
-            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b1, 0x130, 0xF, 0xF, false);
-            const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b2, 0x130, 0xF, 0xF, false);
-            // boundary bits of the positions p0 .. p0 + 63 (bit k: a run starts at p0 + k)
-            const uint32_t sh = (uint32_t)(p0 & 31u);
-            const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
-            const uint64_t BND = sh ? ((lo64 >> sh) | ((uint64_t)w2 << (64u - sh))) : lo64;
-            const bool cont = in && (b0 & 0xC0u) == 0x80u;
-            const bool lead = in && b0 >= 0xC0u;
-            const uint32_t need = b0 >= 0xF8u ? 99u : b0 >= 0xF0u ? 3u : b0 >= 0xE0u ? 2u : b0 >= 0xC2u ? 1u : 99u;
-            bool lead_ok = false;
-            if (lead && lane <= 60) {
-                lead_ok = need != 99u && p + need < s1;
-                if (lead_ok) {
-                    const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
-                    lead_ok = c1 && (need < 2u || c2) && (need < 3u || c3);
-                    const uint64_t cut = (BND >> (lane + 1)) & ((1ull << need) - 1ull);     // a run starts inside the sequence
-                    if (cut) lead_ok = false;
-                    if (b0 == 0xE0u && b1 < 0xA0u) lead_ok = false;   // overlong 3-byte
-                    if (b0 == 0xEDu && b1 >= 0xA0u) lead_ok = false;  // surrogates
-                    if (b0 == 0xF0u && b1 < 0x90u) lead_ok = false;   // overlong 4-byte
-                    if (b0 == 0xF4u && b1 >= 0x90u) lead_ok = false;  // > U+10FFFF
-                    if (b0 > 0xF4u) lead_ok = false;
-                }
-                if (!lead_ok) err = true;
-            }
-            // the positions the valid leads of this window claim
-            const uint64_t L1 = __ballot(lead_ok), L2 = __ballot(lead_ok && need >= 2u), L3 = __ballot(lead_ok && need >= 3u);
-            const uint64_t claimed = (L1 << 1) | (L2 << 2) | (L3 << 3);
-            // (in a later step the lanes 0..2 were judged as lanes 58..60 of the step before)
-            if (cont && lane <= 60 && (lane >= 3 || p0 == s0) && !((claimed >> lane) & 1ull)) err = true;
         }
         if (__ballot(err) && lane == 0) atomicMin(a.err + 2, (unsigned long long)d);
     }

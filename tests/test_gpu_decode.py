@@ -123,10 +123,13 @@ def test_full_size_round_trip_device_resident(tk, bench_vocab):
 
 
 def test_utf8_validation_at_every_window_offset(tk, eng, test_vocab):
-    """tk_decode_validate_kernel judges 64 bytes per step with windows that overlap by six: every kind of sequence -- valid
-    2 / 3 / 4-byte code points, a lone continuation byte, a truncated lead, overlong forms, a surrogate, a code point beyond
-    U+10FFFF, a special token inside a code point (two runs, each invalid alone) -- at every offset 0..130 of a document, so
-    that each straddles the window seams in every way; the failing document is the one python's own decoder rejects."""
+    """tk_decode_validate_kernel judges 256 bytes per step, one aligned dword per lane, every lane inside a twelve-byte window
+    {left neighbour's dword, own, right neighbour's} (round 2: 64 bytes per step, windows overlapping by six): every kind of
+    sequence -- valid 2 / 3 / 4-byte code points, a lone continuation byte, a truncated lead, overlong forms, a surrogate, a code
+    point beyond U+10FFFF, a special token inside a code point (two runs, each invalid alone) -- at every offset 0..130, 236..279
+    and 500..519 of a document, so that each straddles the dword, lane and step seams (at 4, 256 and 512 bytes from the
+    document's aligned start, which the documents in front shift through all four residues) in every way; the failing document
+    is the one python's own decoder rejects."""
     ns = test_vocab["num_special"]
     P = tk.SpecialTokenPolicy
 
@@ -135,7 +138,8 @@ def test_utf8_validation_at_every_window_offset(tk, eng, test_vocab):
 
     valid = ["é".encode(), "中".encode(), "\U0001f680".encode(), "é中\U0001f680".encode()]
     docs = []
-    for k in range(0, 131):
+    offsets = list(range(0, 131)) + list(range(236, 280)) + list(range(500, 520))
+    for k in offsets:
         for v in valid:
             docs.append(byte_ids(b"a" * k + v + b"b" * 70 + v))
     texts = eng.decode_docs(docs, P.Ignore)
@@ -144,7 +148,7 @@ def test_utf8_validation_at_every_window_offset(tk, eng, test_vocab):
            bytes([0xED, 0xA0, 0x80]), bytes([0xF4, 0x90, 0x80, 0x80]), bytes([0xF8, 0x88, 0x80, 0x80]), bytes([0xE4, 0xB8, 0x41]),
            bytes([0xC3, 0xC3, 0xA9])]
     filler = [byte_ids(("zé中" * 40).encode()) for _ in range(5)]
-    for k in list(range(0, 131, 1)):
+    for k in offsets:
         for bseq in bad[k % 3::3]:                       # (a third of the kinds per offset: every kind meets every residue of 58)
             raw = b"a" * k + bseq + b"b" * 9
             with pytest.raises(UnicodeDecodeError):

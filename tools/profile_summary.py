@@ -39,7 +39,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(go, "prof_%s" % tag, "%s_kernel_stats.csv" % tag), os.path.join(out, "%s_kernel_stats.csv" % tag))
     bench = None
-    for cfg in ("c2", "c3", "c3_vocab50k", "zipf", "zipf4m"):
+    for cfg in ("c2", "c2_heldout", "c3", "c3_vocab50k", "zipf", "zipf_serial_tail", "zipf4m"):
         bpath = os.path.join(go, "bench_%s_%s.json" % (tag, cfg))
         if not os.path.exists(bpath):
             continue
@@ -67,6 +67,14 @@ def main():
     if os.path.exists(cj):
         with open(cj) as f, open(os.path.join(out, "%s_cjk_probe.txt" % tag), "w") as g:
             g.writelines(l for l in f if l.startswith("runs of"))
+    # kernel stats and one-step timelines of the other shapes (tools/trace_step.sh <tag>_c3 / <tag>_zipf)
+    for cfg in ("c3", "zipf"):
+        for f in glob.glob(os.path.join(go, "trace_%s_%s" % (tag, cfg), "**", "*_kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(out, "%s_kernel_stats_%s.csv" % (tag, cfg)))
+        tl = os.path.join(go, "trace_%s_%s_timeline.txt" % (tag, cfg))
+        if os.path.exists(tl):
+            with open(tl) as f, open(os.path.join(out, "%s_timeline_%s.txt" % (tag, cfg)), "w") as g:
+                g.writelines(l for l in f if "rocclr" not in l or "step span" in l)
     benches = {}
     for cfg in ("c2", "c3", "zipf"):
         bp = os.path.join(out, "%s_bench_%s.json" % (tag, cfg))

@@ -272,12 +272,25 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
             if (q + 4 > s1) w &= 0xFFFFFFFFu >> (8u * (uint32_t)(q + 4 - s1));
             return w;
         };
+        // run-start bits of the positions q - 4 .. q + 27 (bit k: a run starts at q - 4 + k); requested with the dword, one step
+        // ahead (a load inside the step -- only steps with a byte >= 0x80 need the bits -- was a memory round trip per step
+        // that nothing hid: the kernel was bound by exactly that, not by its instructions)
+        auto load_rb = [&](uint64_t q) -> uint32_t {
+            if (q >= s1) return 0u;
+            if (q < 4) return a.run_bits[0] << 4;
+            const uint64_t rb = q - 4;
+            const uint32_t r0 = a.run_bits[rb >> 5], r1 = a.run_bits[(rb >> 5) + 1];
+            const uint32_t sh = (uint32_t)(rb & 31u);
+            return sh ? ((r0 >> sh) | (r1 << (32u - sh))) : r0;
+        };
         uint32_t nw = load(A0 + 4ull * (uint64_t)lane);
+        uint32_t nrb = load_rb(A0 + 4ull * (uint64_t)lane);
         uint32_t carry = 0u;                        // the dword in front of the step's first one (in front of the document: NUL)
         for (uint64_t p0 = A0; p0 < s1; p0 += 256) {
             const uint64_t q = p0 + 4ull * (uint64_t)lane;
-            const uint32_t w = nw;
+            const uint32_t w = nw, RB = nrb;
             nw = load(q + 256);
+            nrb = load_rb(q + 256);
             const uint32_t first_next = (uint32_t)__builtin_amdgcn_readlane((int)nw, 0);
             uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1: lane l <- lane l - 1
             uint32_t xw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false);   // wave_shl:1: lane l <- lane l + 1
@@ -286,16 +299,6 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
             carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
             if (__builtin_amdgcn_ballot_w64((w & 0x80808080u) != 0u) == 0ull) continue;               // an ASCII step (wave-uniform)
             if ((w & 0x80808080u) != 0u && q < s1) {
-                // run-start bits of the positions q - 4 .. q + 27 (bit k: a run starts at q - 4 + k)
-                uint32_t RB;
-                if (q >= 4) {
-                    const uint64_t rb = q - 4;
-                    const uint32_t r0 = a.run_bits[rb >> 5], r1 = a.run_bits[(rb >> 5) + 1];
-                    const uint32_t sh = (uint32_t)(rb & 31u);
-                    RB = sh ? ((r0 >> sh) | (r1 << (32u - sh))) : r0;
-                } else {
-                    RB = a.run_bits[0] << 4;
-                }
                 const uint64_t fwd = (uint64_t)w | ((uint64_t)xw << 32);    // bytes q .. q + 7
                 const uint64_t back = (uint64_t)pw | ((uint64_t)w << 32);   // bytes q - 4 .. q + 3
 #pragma unroll

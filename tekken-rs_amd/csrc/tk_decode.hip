@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "tk_kernels.h"
+#include "tk_utf8_swar.h"
 
 #define TKD_BLOCK 256
 
@@ -244,15 +245,16 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     }
 }
 
-// One wave per document, FOUR BYTES PER LANE: 256 bytes per step, one aligned dword per lane (the same checks as
-// tk_validate_kernel -- RFC 3629 -- with the extra rule that positions flagged in run_bits cut sequences).  A lane judges the
-// four bytes of its dword inside a twelve-byte window {previous lane's dword, its own, the next lane's}: a LEAD byte checks the
-// bytes it claims (count, ranges, no run start inside the sequence, all of it inside the document), a CONTINUATION byte only
-// that some lead in the three bytes before it claims it (that lead's own check settles the rest).  The neighbour dwords come from
-// DPP shifts; lane 0's left neighbour is the last dword of the step before (a scalar carried along), lane 63's right neighbour
-// lane 0 of the step after (loaded one step ahead with the rest).  The run-start bits of the window come from two words of
-// run_bits per lane.  Bytes outside the document read as NUL, which claims nothing and needs nothing.
-// (Round 2's form took one lane per byte, 58 bytes per step at about a hundred instructions: 5.8 of the 10.7 ms of a C3 decode.)
+// One wave per document, FOUR BYTES PER LANE in one register: 256 bytes per step, one aligned dword per lane, all four bytes
+// judged at once by tku8_err4 (tk_utf8_swar.h: the three-table look-up of Keiser & Lemire with byte permutes, run starts as hard
+// boundaries -- the same checks as tk_validate_kernel, RFC 3629, with the extra rule that positions flagged in run_bits cut
+// sequences).  A lane needs the dword in front of its own (DPP shift; lane 0: the last dword of the step before, a scalar
+// carried along) and the run-start bits of the six positions around its dword (two words of run_bits, requested with the dword
+// one step ahead).  Bytes outside the document read as NUL; the dword that holds the position BEHIND the document is judged too
+// (a NUL behind an open sequence is "too short").
+// (Round 2: one lane per byte, 58 bytes per step, ~100 instructions a step -- 5.8 of the 10.7 ms of a C3 decode.  Four bytes per
+// lane with a lead / continuation branch per byte was no better, 4.7 ms: both branches run for every byte of non-ASCII text,
+// ~300 instructions per 256 bytes.  This form: ~70.)
 __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKD_BLOCK / 64) + (threadIdx.x >> 6);
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
         if (s1 == s0) continue;
         bool err = false;
         const uint64_t A0 = s0 & ~3ull;
-        // the dword at q, bytes outside [s0, s1) as NUL (out_bytes is allocated in whole dwords)
+        // the dword at q, bytes outside [s0, s1) as NUL (out_bytes is allocated in whole dwords, with slack)
         auto load = [&](uint64_t q) -> uint32_t {
             if (q >= s1 || q + 4 <= s0) return 0u;
             uint32_t w = *reinterpret_cast<const uint32_t*>(b + q);
@@ -272,11 +274,9 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
             if (q + 4 > s1) w &= 0xFFFFFFFFu >> (8u * (uint32_t)(q + 4 - s1));
             return w;
         };
-        // run-start bits of the positions q - 4 .. q + 27 (bit k: a run starts at q - 4 + k); requested with the dword, one step
-        // ahead (a load inside the step -- only steps with a byte >= 0x80 need the bits -- was a memory round trip per step
-        // that nothing hid: the kernel was bound by exactly that, not by its instructions)
+        // run-start bits of the positions q - 4 .. q + 27 (bit k: a run starts at q - 4 + k)
         auto load_rb = [&](uint64_t q) -> uint32_t {
-            if (q >= s1) return 0u;
+            if (q > s1) return 0u;
             if (q < 4) return a.run_bits[0] << 4;
             const uint64_t rb = q - 4;
             const uint32_t r0 = a.run_bits[rb >> 5], r1 = a.run_bits[(rb >> 5) + 1];
@@ -286,54 +286,16 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_validate_kernel(TkDecodeA
         uint32_t nw = load(A0 + 4ull * (uint64_t)lane);
         uint32_t nrb = load_rb(A0 + 4ull * (uint64_t)lane);
         uint32_t carry = 0u;                        // the dword in front of the step's first one (in front of the document: NUL)
-        for (uint64_t p0 = A0; p0 < s1; p0 += 256) {
+        for (uint64_t p0 = A0; p0 <= s1; p0 += 256) {
             const uint64_t q = p0 + 4ull * (uint64_t)lane;
             const uint32_t w = nw, RB = nrb;
             nw = load(q + 256);
             nrb = load_rb(q + 256);
-            const uint32_t first_next = (uint32_t)__builtin_amdgcn_readlane((int)nw, 0);
             uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1: lane l <- lane l - 1
-            uint32_t xw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false);   // wave_shl:1: lane l <- lane l + 1
             if (lane == 0) pw = carry;
-            if (lane == 63) xw = first_next;
             carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
-            if (__builtin_amdgcn_ballot_w64((w & 0x80808080u) != 0u) == 0ull) continue;               // an ASCII step (wave-uniform)
-            if ((w & 0x80808080u) != 0u && q < s1) {
-                const uint64_t fwd = (uint64_t)w | ((uint64_t)xw << 32);    // bytes q .. q + 7
-                const uint64_t back = (uint64_t)pw | ((uint64_t)w << 32);   // bytes q - 4 .. q + 3
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint64_t p = q + k;
-                    const uint32_t b0 = (uint32_t)(fwd >> (8u * k)) & 0xFFu;
-                    if (b0 < 0x80u || p < s0 || p >= s1) continue;
-                    if (b0 >= 0xC0u) {
-                        const uint32_t b1 = (uint32_t)(fwd >> (8u * k + 8u)) & 0xFFu, b2 = (uint32_t)(fwd >> (8u * k + 16u)) & 0xFFu,
-                                       b3 = (uint32_t)(fwd >> (8u * k + 24u)) & 0xFFu;
-                        const uint32_t need = b0 >= 0xF8u ? 99u : b0 >= 0xF0u ? 3u : b0 >= 0xE0u ? 2u : b0 >= 0xC2u ? 1u : 99u;
-                        bool ok = need != 99u && p + need < s1;
-                        if (ok) {
-                            const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
-                            ok = c1 && (need < 2u || c2) && (need < 3u || c3);
-                            if ((RB >> (4u + k + 1u)) & ((1u << need) - 1u)) ok = false;     // a run starts inside the sequence
-                            if (b0 == 0xE0u && b1 < 0xA0u) ok = false;   // overlong 3-byte
-                            if (b0 == 0xEDu && b1 >= 0xA0u) ok = false;  // surrogates
-                            if (b0 == 0xF0u && b1 < 0x90u) ok = false;   // overlong 4-byte
-                            if (b0 == 0xF4u && b1 >= 0x90u) ok = false;  // > U+10FFFF
-                            if (b0 > 0xF4u) ok = false;
-                        }
-                        if (!ok) err = true;
-                    } else {
-                        // a continuation byte: claimed by a lead one, two or three bytes back, nothing but continuation bytes and
-                        // no run start in between (a run that starts AT p cuts as well)
-                        const uint32_t m1 = (uint32_t)(back >> (8u * k + 24u)) & 0xFFu, m2 = (uint32_t)(back >> (8u * k + 16u)) & 0xFFu,
-                                       m3 = (uint32_t)(back >> (8u * k + 8u)) & 0xFFu;
-                        const uint32_t rb = RB >> (4u + k - 2u);             // bit 0: p - 2, bit 1: p - 1, bit 2: p
-                        const bool k1 = (m1 & 0xC0u) == 0x80u, k2 = (m2 & 0xC0u) == 0x80u;
-                        const bool cl = (m1 >= 0xC0u && !(rb & 4u)) || (k1 && m2 >= 0xE0u && !(rb & 6u)) || (k1 && k2 && m3 >= 0xF0u && !(rb & 7u));
-                        if (!cl) err = true;
-                    }
-                }
-            }
+            if (__builtin_amdgcn_ballot_w64(((w | pw) & 0x80808080u) != 0u) == 0ull) continue;        // an ASCII step (wave-uniform)
+            if (q <= s1 && tku8_err4(pw, w, RB) != 0u) err = true;
         }
         if (__ballot(err) && lane == 0) atomicMin(a.err + 2, (unsigned long long)d);
     }

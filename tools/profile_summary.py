@@ -106,6 +106,11 @@ def summarize(tag, sfx, bench, tpath, sqpath, go):
                 allc[k][cname].extend(v)
     mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in allc.items()}
     git = (bench or {}).get("build", {}).get("git")
+    try:   # the commit of the library the passes ran on (written by __graft_entry__.build(); the same file bench.py stamps its line with)
+        with open(os.path.join(ROOT, "tekken-rs_amd", "BUILD_INFO.json")) as f:
+            git = json.load(f).get("git") or git
+    except Exception:  # noqa: BLE001
+        pass
     res = {"round": tag, "git": git, "shape": (bench or {}).get("config", {}).get("workload"),
            "command": "tools/pmc_flat.sh %s %s...: one rocprofv3 --pmc <group> --kernel-trace --output-format csv pass per counter group over "
                       "python3 bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 <shape>" % (tag, sfx),

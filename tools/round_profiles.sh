@@ -6,6 +6,27 @@ tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
+# 1. kernel traces and PMC passes first; their summary (profiles/hbm_traffic*.json, stamped with this build's commit) is written on
+#    the box so that the bench lines of step 2 carry traffic and VALU floor measured at the SAME commit
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag} -o ${tag} -- python3 $root/bench.py --steps 20 --warmup 2 --cpu-passes 0 --host-steps 0 --single-docs 0 > $out/prof_${tag}.log 2>&1 || exit 1
+echo "kernel trace (c2) done"
+cd $root
+bash tools/trace_step.sh ${tag}_c3 --kind mixed --doc-len 2048 --docs 1000000 --steps 3 --warmup 1 > /dev/null || exit 1
+echo "kernel trace + timeline (c3) done"
+bash tools/trace_step.sh ${tag}_zipf --kind zipf --docs 500000 --steps 3 --warmup 1 > /dev/null || exit 1
+echo "kernel trace + timeline (zipf) done"
+tools/pmc_flat.sh ${tag} "" || exit 1
+tools/pmc_flat.sh ${tag} _c3 --kind mixed --doc-len 2048 --docs 1000000 || exit 1
+tools/pmc_flat.sh ${tag} _zipf --kind zipf --docs 500000 || exit 1
+for cfg in c2 c3 zipf; do   # (the summary wants each shape's algorithmic byte count: a short bench line)
+  case $cfg in c2) A="";; c3) A="--kind mixed --doc-len 2048";; zipf) A="--kind zipf --docs 500000";; esac
+  [ -f profiles/${tag}_bench_$cfg.json ] || timeout -k 10 300 python bench.py $A --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > profiles/${tag}_bench_$cfg.json 2>/dev/null
+done
+python tools/profile_summary.py ${tag} > $out/profile_summary_${tag}.log 2>&1 || { tail -5 $out/profile_summary_${tag}.log; exit 1; }
+mkdir -p $out/profiles_${tag} && cp profiles/hbm_traffic*.json profiles/${tag}_sq_counters*.json $out/profiles_${tag}/
+echo "PMC summary written"
+# 2. the bench lines
 Q="--decode-steps 0 --host-steps 0 --single-docs 0"
 timeout -k 10 300 python bench.py > $out/bench_${tag}_c2.json 2> $out/bench_${tag}_c2.err || exit 1
 echo "c2 done"
@@ -23,15 +44,4 @@ timeout -k 10 200 python tools/load_time.py > $out/load_time_${tag}.json 2> $out
 echo "load time done"
 timeout -k 10 200 python tools/gpu_longpiece_time.py > $out/longpiece_time_${tag}.txt 2> /dev/null || exit 1
 echo "long piece timing done"
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag} -o ${tag} -- python3 $root/bench.py --steps 20 --warmup 2 --cpu-passes 0 --host-steps 0 --single-docs 0 > $out/prof_${tag}.log 2>&1 || exit 1
-echo "kernel trace (c2) done"
-cd $root
-bash tools/trace_step.sh ${tag}_c3 --kind mixed --doc-len 2048 --docs 1000000 --steps 3 --warmup 1 > /dev/null || exit 1
-echo "kernel trace + timeline (c3) done"
-bash tools/trace_step.sh ${tag}_zipf --kind zipf --docs 500000 --steps 3 --warmup 1 > /dev/null || exit 1
-echo "kernel trace + timeline (zipf) done"
-tools/pmc_flat.sh ${tag} "" || exit 1
-tools/pmc_flat.sh ${tag} _c3 --kind mixed --doc-len 2048 --docs 1000000 || exit 1
-tools/pmc_flat.sh ${tag} _zipf --kind zipf --docs 500000 || exit 1
 echo "all done"

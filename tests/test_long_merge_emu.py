@@ -30,8 +30,8 @@ def test_block_merges_on_adversarial_vocabularies():
     equal pairs: even offsets across step and wave boundaries), lengths around every boundary of the layout: one step (64),
     one part per thread (1024), two steps per wave (2048)."""
     rng = random.Random(9)
-    for alphabet, n_extra, max_len, sizes in (("ab", 60, 6, (65, 128, 1025)), ("abc", 250, 5, (66, 129, 1024, 2049)),
-                                              ("abcdefgh", 300, 5, (65, 1023, 2048, 4100))):
+    for alphabet, n_extra, max_len, sizes in (("ab", 60, 6, (65, 128, 1025)), ("abc", 250, 5, (66, 129, 1024)),
+                                              ("abcdefgh", 300, 5, (65, 1023, 2049, 4100))):
         toks = gg.vocab_adversarial(rng, alphabet, n_extra, max_len)
         if os.environ.get("TK_TEST_SANITIZE"):      # (the sanitizer leg of tests/test_sanitizers.py: three times slower)
             if alphabet == "abcdefgh":

@@ -46,27 +46,24 @@ def main():
         with open(bpath) as f, open(os.path.join(out, "%s_bench_%s.json" % (tag, cfg)), "w") as g:
             for line in f:
                 if line.startswith("{"):
+                    # (round 3: the PMC passes are taken per shape -- tools/pmc_flat.sh <tag> [<suffix> <shape>] -- and bench.py quotes
+                    # the file of ITS shape; a line of any other shape carries null by itself)
+                    g.write(line)
                     if cfg == "c2":
-                        g.write(line)
                         bench = json.loads(line)
-                    else:
-                        # the PMC traffic figure belongs to the C2 workload it was measured on (bench.py reports null for any
-                        # other shape; lines written by an older bench.py carried the C2 figure along)
-                        d = json.loads(line)
-                        for k in ("traffic", "traffic_pipeline", "traffic_measured_at", "traffic_source"):
-                            if k in d.get("roofline", {}):
-                                d["roofline"][k] = None
-                        g.write(json.dumps(d) + "\n")
     lt = os.path.join(go, "load_time_%s.json" % tag)
     if os.path.exists(lt):
         shutil.copy(lt, os.path.join(out, "%s_load_time.json" % tag))
+    fz = os.path.join(go, "gpu_fuzz_%s.txt" % tag)
+    if os.path.exists(fz):
+        shutil.copy(fz, os.path.join(out, "%s_gpu_fuzz.txt" % tag))
     lp = os.path.join(go, "longpiece_time_%s.txt" % tag)
     if os.path.exists(lp):
         shutil.copy(lp, os.path.join(out, "%s_longpiece_time.txt" % tag))
     cj = os.path.join(go, "cjk_probe_%s.txt" % tag)
     if os.path.exists(cj):
         with open(cj) as f, open(os.path.join(out, "%s_cjk_probe.txt" % tag), "w") as g:
-            g.writelines(l for l in f if l.startswith("runs of"))
+            g.writelines(l for l in f if l.startswith("runs of") or l.startswith("=="))
     # kernel stats and one-step timelines of the other shapes (tools/trace_step.sh <tag>_c3 / <tag>_zipf)
     for cfg in ("c3", "zipf"):
         for f in glob.glob(os.path.join(go, "trace_%s_%s" % (tag, cfg), "**", "*_kernel_stats.csv"), recursive=True):

@@ -131,7 +131,7 @@ TK_DEV uint32_t tk_probe_long(const TkTablesView& t, uint32_t h1, uint32_t h2, u
 
 // KEY64 (tk_hash.h): the whole-piece look-up of a piece of 17..64 bytes by ONE LANE, the piece's bytes as dwords -- tw = the
 // aligned word of the text copy that holds its first byte, sh = that byte's offset in it (the words behind the piece are
-// readable).  One multiply per dword and hash, the verification against the blob by dwords too.
+// readable).  One multiply per dword, the verification against the blob by dwords too.
 TK_DEV uint32_t tk_load_u32_unaligned(const uint8_t* p) {
     typedef uint32_t __attribute__((aligned(1))) u32_u;
     return *reinterpret_cast<const u32_u*>(p);
@@ -139,17 +139,18 @@ TK_DEV uint32_t tk_load_u32_unaligned(const uint8_t* p) {
 TK_DEV uint32_t tk_probe_key64(const TkTablesView& t, const uint32_t* tw, uint32_t sh, uint32_t len) {
     const uint32_t nd = (len + 3u) >> 2;
     const uint32_t tail = (len & 3u) ? ((1u << (8u * (len & 3u))) - 1u) : 0xFFFFFFFFu;
-    uint32_t ha = 0, hb = 0;
+    uint32_t ha = 0;
     {
         uint32_t lo = tw[0];
         for (uint32_t j = 0; j < nd; ++j) {
             const uint32_t hi = tw[j + 1];
             uint32_t w = wv_alignbyte(hi, lo, sh);
             if (j + 1u == nd) w &= tail;
-            tk_k64_step(ha, hb, w);
+            tk_k64_step(ha, w);
             lo = hi;
         }
     }
+    const uint32_t hb = tk_k64_tag(ha);
     uint32_t s = tk_k64_slot(ha, len) & t.key64_mask;
     for (uint32_t tries = 0; tries <= t.key64_mask; ++tries) {
         const tk_u32x4 e = *reinterpret_cast<const tk_u32x4*>(t.key64_tab + s);  // {tag, rank, len, blob_off}

@@ -105,14 +105,13 @@ TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
 TK_HD uint32_t tk_pair_fbit(uint32_t h) { return h >> (32 - TK_PAIRF_LOG2); }
 
 /* KEY64: whole pieces of 17..64 bytes as the FLAT kernel looks them up -- one lane per piece, the bytes as little-endian
-   dwords (the last one zero padded), one multiply per dword and hash (the polynomial byte hash of LONG, which the
-   per-document kernels compute with one lane per byte, cost this kernel two multiplies and a dependent load per BYTE).
-   Entries like LONG: {tag = hb, rank, len, blob_off}, linear probing from tk_k64_slot(ha, len), verified against the blob. */
-TK_HD void tk_k64_step(uint32_t& ha, uint32_t& hb, uint32_t w) {
-    ha = (ha ^ w) * 0x9E3779B1u;
-    hb = (hb + w) * 0x85EBCA77u;
-}
+   dwords (the last one zero padded), ONE multiply per dword (the polynomial byte hash of LONG, which the per-document
+   kernels compute with one lane per byte, cost this kernel two multiplies and a dependent load per BYTE).
+   Entries like LONG: {tag, rank, len, blob_off}, linear probing from tk_k64_slot(ha, len), tag = tk_k64_tag(ha), verified
+   against the blob. */
+TK_HD void tk_k64_step(uint32_t& ha, uint32_t w) { ha = (ha ^ w) * 0x9E3779B1u + (ha >> 15); }
 TK_HD uint32_t tk_k64_slot(uint32_t ha, uint32_t len) { return tk_fmix32(ha + len * 0x165667B1u); }
+TK_HD uint32_t tk_k64_tag(uint32_t ha) { return tk_fmix32(ha ^ 0x85EBCA77u); }   /* other bits of the same hash: the blob compare decides */
 
 /* cut rule (tk_tables.cpp make_cut_tables): exact bit maps over byte bigrams / trigrams */
 #define TK_CUT_K2_WORDS (1u << 11)       /* 2^16 bits */

@@ -62,15 +62,15 @@ void TkHostTables::make_cut_tables() {
             const uint8_t* p = blob.data() + offs[r];
             const uint32_t len = offs[r + 1] - offs[r];
             if (len < 17u || len > 64u) continue;
-            uint32_t ha = 0, hb = 0;
+            uint32_t ha = 0;
             for (uint32_t j = 0; j < len; j += 4) {
                 uint32_t w = 0;
                 for (uint32_t k = 0; k < 4 && j + k < len; ++k) w |= (uint32_t)p[j + k] << (8 * k);
-                tk_k64_step(ha, hb, w);
+                tk_k64_step(ha, w);
             }
             uint32_t sl = tk_k64_slot(ha, len) & key64_mask;
             while (key64_tab[sl].len) sl = (sl + 1) & key64_mask;
-            key64_tab[sl] = tk_long_entry{hb, r, len, offs[r]};
+            key64_tab[sl] = tk_long_entry{tk_k64_tag(ha), r, len, offs[r]};
         }
     }
     cut_k2.assign(TK_CUT_K2_WORDS, 0u);

@@ -121,6 +121,7 @@ struct TkfClass {
     uint32_t L, N, S, NL, SP, AP, HI, STMD, RV, E, LL;
     uint32_t U8C, LEAD, C5, BF;  // UTF-8: continuation bytes, lead bytes; C5 BF = U+017F (folds to 's')
     uint32_t UP, SL, X, M;    // upper-case letters, '/', neutral letters (Lm | Lo), marks (the JSON pattern of row f-3 only)
+    uint32_t F2, F3;          // lead bytes of 2- / 3-byte chars that the RANGE RULES know to be letters (tkf_classify; 0 in an ASCII region)
     bool nmb;                 // wave-uniform: the region holds a multi-byte \p{N} char
 };
 
@@ -182,6 +183,33 @@ TK_DEV TkfClass tkf_classify(const uint32_t* x) {
     c.X = 0u;
     c.M = 0u;
     c.nmb = false;
+    c.F2 = 0u;
+    c.F3 = 0u;
+    if (tkf_any(p7)) {
+        // Range rules for the big letter blocks, as mask algebra on the planes (one instruction = 2048 bytes): a char they cover needs
+        // no decode and no table look-up -- the per-char walk of tk_flat_chunk (two chars per round and lane: a third of this
+        // kernel on mixed UTF-8 text) is left with what the rules do not cover.  Every rule names (lead byte, range of the
+        // second byte) whose WHOLE block of code points is class L in the trie (tests/test_flat_path.py checks every code point
+        // of the BMP through this path against the oracle, which reads the trie):
+        //   3 bytes: E4 B8..BF, E5..E8, E9 80..BD (CJK unified U+4E00..9F7F); EA B0..BF, EB, EC, ED 80..9D (Hangul U+AC00..D77F)
+        //   2 bytes: C3 except 97 / B7 (U+00C0..00FF without the two operators); D0, D1 80..8F (Cyrillic U+0400..044F);
+        //            CE B1..BF, CF 80..8F (Greek U+03B1..03CF); D8 A0..BF (Arabic U+0620..063F)
+        // The bytes behind the lead must be continuation bytes (anything else is for the walk to judge).
+#define NX(m) tkf_shr((m), 1)
+        const uint32_t cont = p7 & ~p6;
+        const uint32_t nc1 = NX(cont), nc2 = tkf_shr(cont, 2);
+        const uint32_t x54 = p5 & p4, x321 = p3 & p2 & p1;
+        const uint32_t n_geB0 = NX(x54), n_geB8 = NX(x54 & p3), n_BEBF = NX(x54 & x321), n_ge90 = NX(p5 | p4), n_geA0 = NX(p5);
+        const uint32_t n_ge9E = NX(p5 | (p4 & x321)), n_B1BF = NX(x54 & (p3 | p2 | p1 | p0)), n_x7 = NX(p4 & ~p3 & p2 & p1 & p0);
+        const uint32_t hE = p7 & p6 & p5 & ~p4, hC = p7 & p6 & ~p5 & ~p4, hD = p7 & p6 & ~p5 & p4;
+        const uint32_t l0 = ~p3 & ~p2 & ~p1 & ~p0, l1 = ~p3 & ~p2 & ~p1 & p0, l3 = ~p3 & ~p2 & p1 & p0, l4 = ~p3 & p2 & ~p1 & ~p0;
+        const uint32_t l5678 = (~p3 & p2 & (p1 | p0)) | (p3 & ~p2 & ~p1 & ~p0);
+        const uint32_t l8 = p3 & ~p2 & ~p1 & ~p0, l9 = p3 & ~p2 & ~p1 & p0, lA = p3 & ~p2 & p1 & ~p0, lB = p3 & ~p2 & p1 & p0;
+        const uint32_t lC = p3 & p2 & ~p1 & ~p0, lD = p3 & p2 & ~p1 & p0, lE = p3 & p2 & p1 & ~p0, lF = p3 & p2 & p1 & p0;
+        c.F3 = hE & nc1 & nc2 & (l5678 | (l4 & n_geB8) | (l9 & ~n_BEBF) | lB | lC | (lA & n_geB0) | (lD & ~n_ge9E));
+        c.F2 = nc1 & ((hC & l3 & ~n_x7) | (hD & l0) | (hD & l1 & ~n_ge90) | (hC & lE & n_B1BF) | (hC & lF & ~n_ge90) | (hD & l8 & n_geA0));
+#undef NX
+    }
     return c;
 }
 
@@ -461,7 +489,13 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     uint32_t nextb = 0;                                     // CUT: the byte behind the region (the last lane's trigram reaches it)
     if (CUT && r1 < n) nextb = (uint32_t)a.bytes[r1];
     TkfClass m = tkf_classify(x);
-    if (tkf_any(m.HI)) {
+    uint32_t walk = m.LEAD;                                 // lead bytes the per-char walk has to look up
+    if (!PAT && tkf_any(m.F2 | m.F3)) {
+        // the chars the range rules cover: letters, all their bytes (a char may reach into the next lane)
+        m.L |= m.F2 | m.F3 | tkf_shl(m.F2 | m.F3, 1) | tkf_shl(m.F3, 2);
+        walk &= ~(m.F2 | m.F3);
+    }
+    if (tkf_any(walk)) {
         // multi-byte code points: every lane walks the lead bytes among its own bytes, decodes the code point, looks its
         // class up in the trie and marks ALL bytes of the char (runs stay contiguous; a char may reach into the next lane)
         uint32_t* cl = lds + TKF_L_CL;
@@ -476,7 +510,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         }
         wv_lds_sync();
         bool nmb = false;
-        uint32_t w = m.LEAD;
+        uint32_t w = walk;
         // the char at byte i of this lane: its code point (0xFFFFFFFF: malformed) and byte length, from the LDS copy of the region
         // (bytes outside [0, n) are zero there)
         auto decode = [&](int i, uint32_t* clen_out) -> uint32_t {

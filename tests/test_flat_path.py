@@ -263,6 +263,30 @@ def test_emu_flat_utf8(test_vocab):
     _emu_check(test_vocab, ["x'\u017f y'\u017fz '\u017f".encode(), ("\uff11" * 300).encode(), ("\u4e2d\u6587" * 10 + " ").encode() * 30])
 
 
+def test_emu_flat_every_bmp_code_point(small_vocab):
+    """The range rules of tkf_classify (CJK unified, Hangul, basic Cyrillic / Greek / Arabic, Latin-1 letters: whole blocks named
+    by lead byte and a range of the second byte, taken as letters without decode or table look-up) and the per-char walk for
+    everything else: EVERY code point of the BMP (and a sample beyond it) between a letter, a digit and a blank, split by the
+    flat path, against the oracle's split, which reads the class trie -- a block that a rule claims and the trie does not hold
+    as letters shows up here."""
+    cps = [c for c in range(0x80, 0x10000) if not 0xD800 <= c <= 0xDFFF] + list(range(0x1F600, 0x1F650)) + list(range(0x20000, 0x20040)) + [0x10FFFF]
+    docs, cur = [], []
+    for c in cps:
+        ch = chr(c)
+        cur.append("a%sb %s1 %s%s " % (ch, ch, ch, ch))
+        if len(cur) == 400:
+            docs.append("".join(cur).encode("utf-8"))
+            cur = []
+    docs.append("".join(cur).encode("utf-8"))
+    ids, starts, flagged = emu.flat_encode_batch(small_vocab["tokens"], small_vocab["num_special"], small_vocab["bos"], small_vocab["eos"], docs, False, False)
+    o = helpers.oracle_for(small_vocab)
+    for i, d in enumerate(docs):
+        if i not in flagged:
+            assert starts[i] == tk_oracle.split(d), (i, d[:60])
+        assert ids[i] == o.encode(d, False, False), i
+    assert len(flagged) < len(docs) // 10
+
+
 def test_key_hash_fallback_mode(test_vocab):
     """Three 12-byte tokens built to have the SAME cheap key hash (mode 0 folds the upper 8 bytes into the lower ones):
     a cuckoo slot pair cannot hold three keys, so the table builder has to fall back to the strong hash (mode 1) --

@@ -15,8 +15,9 @@ d, ab = sys.argv[1], sys.argv[2]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if r["Kernel_Name"].startswith(("tk_flat_kernel", "tk_flat_dbg_kernel")):
+    if r["Kernel_Name"].startswith(("tk_flat_kernel", "tk_flat_dbg_kernel", "tk_flat_split_kernel")):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc["ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 print("ablate", ab, {k: round(sum(v) / len(v) / 1e6, 2) for k, v in sorted(acc.items())}, "(millions per launch)")
 PY
 done

@@ -1260,15 +1260,20 @@ TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane,
     tk_merge_items64(a, have, rec, (uint32_t)chunk, lane, mlds, filt);
 }
 
-// sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of two
-// N x 64 word arrays (word i * 64 + l, so whatever positions the lanes index, a wave's access is free of bank
-// conflicts, and no lane ever touches another one's words: no barrier).  Parts never move: bit i of `alive` says that
-// a part starts at byte i, tok[i] is its id and key[i] = (rank of the pair (part i, its successor) << 5) | i, or all
-// ones -- so the leftmost smallest rank is one unsigned minimum over the column (v_min3: half an instruction per
-// entry), and a merge is a handful of bit operations and five LDS accesses.  (Parts in N-wide register arrays,
-// shifted by predication -- the first form of this -- cost ~3x (N = 16) to ~4x (N = 32) the VALU issues per merge
-// and 95 / 153 VGPRs.)
-#define TKM_LDS_WORDS(N) (2 * (N) * 64)
+// sequential merge of one piece of up to N bytes per lane (N = 8, 16, 32), parts in LDS: lane l owns column l of an
+// N x 64 word array of KEYS and an N / 4 x 64 word array holding the piece's BYTES (word i * 64 + l, so whatever positions
+// the lanes index, a wave's access is free of bank conflicts, and no lane ever touches another one's words: no barrier).
+// Parts never move: bit i of `alive` says that a part starts at byte i and key[i] = (rank of the pair (part i, its
+// successor) << PB) | i, or all ones -- so the leftmost smallest rank is one unsigned minimum over the column (v_min3: half
+// an instruction per entry), and a merge is a handful of bit operations and a few LDS accesses.  The ID of a part needs no
+// column of its own: a part of one byte is that byte, and a part of several bytes has a dead position right behind its first
+// one -- key[i + 1], which no minimum may pick any more, holds 0x80000000 | id (anything from 0x80000000 up loses against
+// every key; ids are below 2^21).  5 N bytes of LDS per lane instead of 8 N: the columns of a wave are what bounds the
+// waves per CU of the merge kernels, and the waves are what hides their chains of dependent PAIR probes.  (Parts in N-wide
+// register arrays, shifted by predication -- the first form of this -- cost ~3x (N = 16) to ~4x (N = 32) the VALU issues
+// per merge and 95 / 153 VGPRs.)
+#define TKM_COMPACT(N) ((N) >= 32)                        /* the classes whose waves per CU are bounded by their columns */
+#define TKM_LDS_WORDS(N) (TKM_COMPACT(N) ? ((N) + (N) / 4) * 64 : 2 * (N) * 64)
 #ifdef TKM_ABLATE   /* timing-only experiments on the merge kernels (never defined in the shipped build) */
 #define TKM_AB(a, bit) (((a).dbg_ablate & (bit)) != 0)
 #else
@@ -1300,23 +1305,44 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                              uint32_t* out, uint32_t* mlds, int lane) {
     typedef typename TkmAlive<N>::type alive_t;
     constexpr uint32_t PB = N > 64 ? 7u : N > 32 ? 6u : 5u, PM = (1u << PB) - 1u;
+    constexpr uint32_t DEAD = 0x80000000u;                  // key[i] >= DEAD: no pair starts at i (all ones), or the id of the part that begins at i - 1
     const TkTablesView& t = a.t;
+    constexpr bool C = TKM_COMPACT(N);
+    // compact: keys, then the piece's bytes; otherwise ids, then keys (a column of ids of its own: fewer instructions per merge,
+    // kept where the block cannot hold more waves anyway)
+    uint32_t* keyc = C ? mlds + lane : mlds + N * 64 + lane;
+    uint32_t* bytc = mlds + N * 64 + lane;
     uint32_t* tokc = mlds + lane;
-    uint32_t* keyc = mlds + N * 64 + lane;
     const uint32_t n = mine ? len : 0u;
+    // the PAIR2 bit map behind the PAIR filter (tk_hash.h): only the kernels of the compact classes copy it into their LDS
+    const uint32_t* p2bits = C && filt ? filt + TK_PAIRF_WORDS : nullptr;
+    if (C) {
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) bytc[q * 64] = kk[q];
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const uint32_t b = (kk[i >> 2] >> (8 * (i & 3))) & 0xFFu;
         const uint32_t b1 = i + 1 < N ? (kk[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : 0u;
         uint32_t key = 0xFFFFFFFFu;
         if ((uint32_t)(i + 1) < n && !TKM_AB(a, 2048)) {
-            const uint32_t r = t.pair2[b | (b1 << 8)];
-            if (r != TK_RANK_MAX) key = (r << PB) | (uint32_t)i;
+            const uint32_t bb = b | (b1 << 8);
+            if (!p2bits || ((p2bits[bb >> 5] >> (bb & 31u)) & 1u)) {       // (most byte pairs of multi-byte text are no tokens: no gather)
+                const uint32_t r = t.pair2[bb];
+                if (r != TK_RANK_MAX) key = (r << PB) | (uint32_t)i;
+            }
         }
-        tokc[i * 64] = b;
+        if (!C) tokc[i * 64] = b;
         keyc[i * 64] = key;
     }
     alive_t alive = tkm_low(n, (const alive_t*)nullptr);
+    // id of the live part at position x (see above)
+    auto tok_at = [&](uint32_t x, alive_t al) -> uint32_t {
+        if (!C) return tokc[x * 64u];
+        const bool multi = x + 1u < n && !tkm_any((alive_t)(al & tkm_bit(x + 1u < (uint32_t)N ? x + 1u : 0u, (const alive_t*)nullptr)));
+        const uint32_t v = multi ? keyc[(x + 1u) * 64u] : bytc[(x >> 2) * 64u];
+        return multi ? v & ~DEAD : (v >> (8u * (x & 3u))) & 0xFFu;
+    };
     bool active = mine && !TKM_AB(a, 1024);
     while (wv_ballot(active)) {
         if (active) {
@@ -1326,7 +1352,7 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                 const uint32_t k = keyc[i * 64];
                 best = k < best ? k : best;
             }
-            if (best == 0xFFFFFFFFu) {
+            if (best >= DEAD) {
                 active = false;
             } else {
                 // the parts at bi and at the next live position j become one part (at bi) whose id is the rank
@@ -1338,10 +1364,11 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                 const bool has_next = tkm_any(above2), has_prev = tkm_any(below);
                 const uint32_t k = has_next ? tkm_ctz(above2) : 0u;
                 const uint32_t p = has_prev ? tkm_msb(below) : 0u;
-                const uint32_t tn = tokc[k * 64], tp = tokc[p * 64];
+                const uint32_t tn = tok_at(k, alive), tp = tok_at(p, alive);   // (neither lives in a word written below: p + 1 <= bi, k + 1 > j)
                 alive = alive & ~tkm_bit(j, (const alive_t*)nullptr);
-                tokc[bi * 64] = rank;
-                keyc[j * 64] = 0xFFFFFFFFu;
+                keyc[j * 64] = 0xFFFFFFFFu;                                   // j's own pair is gone ...
+                if (C) keyc[(bi + 1u) * 64] = DEAD | rank;                    // ... and the word behind bi (dead: j or an older one) takes the new id
+                else tokc[bi * 64] = rank;
                 uint32_t r_next = TK_RANK_MAX, r_prev = TK_RANK_MAX;
                 tk_probe_pair_x2f(t, filt, has_next, rank, tn, has_prev, tp, rank, r_next, r_prev);
                 keyc[bi * 64] = r_next == TK_RANK_MAX ? 0xFFFFFFFFu : ((r_next << PB) | bi);
@@ -1360,7 +1387,7 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t pos = tkm_any(rem) ? tkm_ctz(rem) : 0u;
-                const uint32_t id = tokc[pos * 64] + t.num_special;
+                const uint32_t id = tok_at(pos, alive) + t.num_special;
                 v[q] = (uint32_t)(q0 + q) < np ? id : TKF_HOLE;
                 rem = tkm_clear_lowest(rem);
             }

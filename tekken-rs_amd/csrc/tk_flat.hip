@@ -138,27 +138,32 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uin
 
 // persistent waves: groups of 64 queued pieces strided over the grid (the host does not know how many there are).
 // Every block keeps the PAIR filter (tk_hash.h) in LDS: a probe whose filter bit is clear issues no gather.
-template <int THREADS, uint32_t WORDS = TK_FILTER_WORDS>
+template <int THREADS, uint32_t WORDS = TK_PAIRF_WORDS>
 TK_DEV void tk_merge_load_filter(const TkFlatArgs& a, uint32_t* filt) {
     const tk_u32x4* src = reinterpret_cast<const tk_u32x4*>(a.t.pair_filter);
     for (uint32_t i = threadIdx.x; i < WORDS / 4; i += THREADS) reinterpret_cast<tk_u32x4*>(filt)[i] = src[i];
     __syncthreads();
 }
 
-// LDS per block: the PAIR filter (32 KB; the wide classes: + the PAIR2 bit map, 8 KB), then every wave's columns (tk_merge_lds:
-// 8 KB for the narrow classes, 10 KB in the compact layout of the wide ones).  One block per CU.
+// LDS per block: the narrow classes keep the PAIR filter (32 KB) in front of every wave's columns (tk_merge_lds: 8 KB); the wide
+// classes spend all of the LDS on columns (10 KB per wave in the compact layout): 16 waves without the filter beat 12 with it
+// (mixed shape, same box: 2.47 against 2.63 ms; 8 waves in the old layout: 3.08).  One block per CU.
 #ifndef TKM_BLOCK
 #define TKM_BLOCK 1024       /* 16 waves (the largest block there is): 32 KB + 16 x 8 KB = 160 KB */
 #endif
 #ifndef TKM_WIDE_BLOCK
-#define TKM_WIDE_BLOCK 768   /* 12 waves: 40 KB + 12 x 10 KB = 160 KB */
+#define TKM_WIDE_BLOCK 1024  /* 16 waves x 10 KB = 160 KB */
 #endif
 #ifndef TKM_FILTER
 #define TKM_FILTER 1
 #endif
 #define TKM_FWORDS (TKM_FILTER ? TK_PAIRF_WORDS : 0u)
 #define TKM_LDS_BYTES ((TKM_FWORDS + (TKM_BLOCK / 64) * TKM_LDS_WORDS(16)) * 4)
-#define TKM_WIDE_LDS_BYTES ((TK_FILTER_WORDS + (TKM_WIDE_BLOCK / 64) * TKM_LDS_WORDS(32)) * 4)
+#ifndef TKM_WIDE_FILTER
+#define TKM_WIDE_FILTER 0
+#endif
+#define TKM_WIDE_FWORDS (TKM_WIDE_FILTER ? TK_PAIRF_WORDS : 0u)
+#define TKM_WIDE_LDS_BYTES ((TKM_WIDE_FWORDS + (TKM_WIDE_BLOCK / 64) * TKM_LDS_WORDS(32)) * 4)
 __global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   // pieces of 2..16 bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
     if (TKM_FILTER) tk_merge_load_filter<TKM_BLOCK, TK_PAIRF_WORDS>(a, wlds);
@@ -171,20 +176,21 @@ __global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   /
 
 __global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
     extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
-    tk_merge_load_filter<TKM_WIDE_BLOCK>(a, wlds);
+    if (TKM_WIDE_FILTER) tk_merge_load_filter<TKM_WIDE_BLOCK, TKM_WIDE_FWORDS>(a, wlds);
+    const uint32_t* wfilt = TKM_WIDE_FILTER ? wlds : nullptr;
     const uint64_t wave = (uint64_t)blockIdx.x * (TKM_WIDE_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_WIDE_BLOCK / 64);
     const uint64_t n2 = a.miss_prefix[3 * a.n_chunks] - a.miss_prefix[2 * a.n_chunks];   // pieces of 17..32 bytes: 64 per wave
     const uint64_t n3 = a.miss_prefix[4 * a.n_chunks] - a.miss_prefix[3 * a.n_chunks];   // pieces of 33..64 bytes: 64 per wave
     const uint64_t w2 = (n2 + 63) / 64, w3 = (n3 + 63) / 64;
-    uint32_t* mlds = wlds + TK_FILTER_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(32);
-    for (uint64_t w = wave; w < w2; w += n_waves) tk_merge_wave<true>(a, w, wv_lane(), mlds, wlds);
+    uint32_t* mlds = wlds + TKM_WIDE_FWORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(32);
+    for (uint64_t w = wave; w < w2; w += n_waves) tk_merge_wave<true>(a, w, wv_lane(), mlds, wfilt);
     if (w3 == 0) return;                                     // (grid-uniform)
     // the class 33..64 bytes needs 64-entry columns: every second wave takes it, with its neighbour's LDS
     __syncthreads();
     if (((threadIdx.x >> 6) & 1u) == 0u) {
         const uint64_t ew = wave >> 1, n_ew = n_waves >> 1;
-        for (uint64_t w = ew; w < w3; w += n_ew) tk_merge_wave_long3(a, w, wv_lane(), mlds, wlds);
+        for (uint64_t w = ew; w < w3; w += n_ew) tk_merge_wave_long3(a, w, wv_lane(), mlds, wfilt);
     }
 }
 
@@ -513,12 +519,12 @@ __global__ __launch_bounds__(256) void tk_flat_long_kernel(TkFlatArgs a, uint32_
     for (uint64_t q = wave_id; q < n; q += n_waves) tk_flat_long_wave(a, pw, (uint32_t)q, lane, my);
 }
 
-// stage two for the records of 65..128 bytes that are no vocabulary keys: one lane per piece (tk_merge_long_wave<128>), two
-// waves per block (32 KB of PAIR filter + 2 x 64 KB of columns), one block per CU.  (The same with 256-entry columns for
+// stage two for the records of 65..128 bytes that are no vocabulary keys: one lane per piece (tk_merge_long_wave<128>), three
+// waves per block (32 KB of PAIR filter + 3 x 40 KB of columns in the compact layout), one block per CU.  (The same with 256-entry columns for
 // 129..256 bytes -- 128 KB per wave, ONE wave per CU -- was measured and dropped: 4.4 ms where the single-wave merge of stage
 // one takes 4.7 ms for the same pieces; 64 chains per CU at ~3 us a round are no better than a dozen at 1.1 us a merge.)
-#define TKM_L128_BLOCK 128
-#define TKM_L128_LDS_BYTES ((TK_FILTER_WORDS + (TKM_L128_BLOCK / 64) * TKM_LDS_WORDS(128)) * 4)
+#define TKM_L128_BLOCK 192
+#define TKM_L128_LDS_BYTES ((TK_PAIRF_WORDS + (TKM_L128_BLOCK / 64) * TKM_LDS_WORDS(128)) * 4)
 template <int N, int BLOCK>
 __device__ __forceinline__ void tk_flat_longN_body(const TkFlatArgs& a, uint32_t* wlds) {
     const uint64_t n = *a.long_count < a.long_cap ? *a.long_count : a.long_cap;
@@ -526,7 +532,7 @@ __device__ __forceinline__ void tk_flat_longN_body(const TkFlatArgs& a, uint32_t
     tk_merge_load_filter<BLOCK>(a, wlds);
     const uint64_t wave = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (BLOCK / 64);
-    uint32_t* mlds = wlds + TK_FILTER_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(N);
+    uint32_t* mlds = wlds + TK_PAIRF_WORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(N);
     for (uint64_t w = wave; w * 64 < n; w += n_waves) tk_merge_long_wave<N>(a, w, wv_lane(), mlds, wlds);
 }
 __global__ __launch_bounds__(TKM_L128_BLOCK) void tk_flat_long128_kernel(TkFlatArgs a) {

@@ -1269,10 +1269,17 @@ TK_DEV void tk_merge_wave_long3(const TkFlatArgs& a, uint64_t wave_id, int lane,
 // column of its own: a part of one byte is that byte, and a part of several bytes has a dead position right behind its first
 // one -- key[i + 1], which no minimum may pick any more, holds 0x80000000 | id (anything from 0x80000000 up loses against
 // every key; ids are below 2^21).  5 N bytes of LDS per lane instead of 8 N: the columns of a wave are what bounds the
-// waves per CU of the merge kernels, and the waves are what hides their chains of dependent PAIR probes.  (Parts in N-wide
+// waves per CU of the merge kernels, and the waves are what hides their chains of dependent PAIR probes.  This COMPACT
+// layout costs ~10 % more instructions per merge: it is used from 32-entry columns on (TKM_COMPACT), where it buys waves --
+// tk_merge_wide_kernel runs 16 waves per CU (no PAIR filter in its LDS either) where it ran 8; the narrow classes keep a
+// column of ids of their own (their block of 16 waves is the largest there is, and with twice the waves and no filter the
+// kernel is slower: 2.76 against 2.49 ms on the mixed shape -- it is bound by its gathers, not by their latency).  (Parts in N-wide
 // register arrays, shifted by predication -- the first form of this -- cost ~3x (N = 16) to ~4x (N = 32) the VALU issues
 // per merge and 95 / 153 VGPRs.)
-#define TKM_COMPACT(N) ((N) >= 32)                        /* the classes whose waves per CU are bounded by their columns */
+#ifndef TKM_COMPACT_MIN
+#define TKM_COMPACT_MIN 32
+#endif
+#define TKM_COMPACT(N) ((N) >= TKM_COMPACT_MIN)           /* the classes whose waves per CU are bounded by their columns */
 #define TKM_LDS_WORDS(N) (TKM_COMPACT(N) ? ((N) + (N) / 4) * 64 : 2 * (N) * 64)
 #ifdef TKM_ABLATE   /* timing-only experiments on the merge kernels (never defined in the shipped build) */
 #define TKM_AB(a, bit) (((a).dbg_ablate & (bit)) != 0)
@@ -1314,8 +1321,6 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
     uint32_t* bytc = mlds + N * 64 + lane;
     uint32_t* tokc = mlds + lane;
     const uint32_t n = mine ? len : 0u;
-    // the PAIR2 bit map behind the PAIR filter (tk_hash.h): only the kernels of the compact classes copy it into their LDS
-    const uint32_t* p2bits = C && filt ? filt + TK_PAIRF_WORDS : nullptr;
     if (C) {
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) bytc[q * 64] = kk[q];
@@ -1326,11 +1331,8 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
         const uint32_t b1 = i + 1 < N ? (kk[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : 0u;
         uint32_t key = 0xFFFFFFFFu;
         if ((uint32_t)(i + 1) < n && !TKM_AB(a, 2048)) {
-            const uint32_t bb = b | (b1 << 8);
-            if (!p2bits || ((p2bits[bb >> 5] >> (bb & 31u)) & 1u)) {       // (most byte pairs of multi-byte text are no tokens: no gather)
-                const uint32_t r = t.pair2[bb];
-                if (r != TK_RANK_MAX) key = (r << PB) | (uint32_t)i;
-            }
+            const uint32_t r = t.pair2[b | (b1 << 8)];
+            if (r != TK_RANK_MAX) key = (r << PB) | (uint32_t)i;
         }
         if (!C) tokc[i * 64] = b;
         keyc[i * 64] = key;

@@ -103,12 +103,6 @@ TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
 #endif
 #define TK_PAIRF_WORDS (1u << (TK_PAIRF_LOG2 - 5))
 TK_HD uint32_t tk_pair_fbit(uint32_t h) { return h >> (32 - TK_PAIRF_LOG2); }
-/* PAIR2 bit map: bit (b0 | b1 << 8) set <=> the two bytes are a token (pair2[...] != TK_RANK_MAX), 8 KB.  It sits right behind
-   the PAIR filter (one buffer, one copy into the merge blocks' LDS): the first pair ranks of a missed piece are one PAIR2
-   gather per byte, and on multi-byte text nearly half of them are for byte pairs that are no tokens -- those are answered
-   from LDS. */
-#define TK_PAIR2_BITS_WORDS (1u << 11)
-#define TK_FILTER_WORDS (TK_PAIRF_WORDS + TK_PAIR2_BITS_WORDS)   /* what the merge blocks keep in LDS */
 
 /* KEY64: whole pieces of 17..64 bytes as the FLAT kernel looks them up -- one lane per piece, the bytes as little-endian
    dwords (the last one zero padded), ONE multiply per dword (the polynomial byte hash of LONG, which the per-document

@@ -28,9 +28,7 @@ static uint32_t pow2_at_least(uint64_t n) {
 }
 
 void TkHostTables::make_pair_filter() {
-    pair_filter.assign(TK_FILTER_WORDS, 0u);
-    for (size_t i = 0; i < pair2.size() && i < 65536u; ++i)      // the PAIR2 bit map, behind the filter words
-        if (pair2[i] != TK_RANK_MAX) pair_filter[TK_PAIRF_WORDS + (i >> 5)] |= 1u << (i & 31u);
+    pair_filter.assign(TK_PAIRF_WORDS, 0u);
     for (uint64_t e : pair_tab) {
         if (e == TK_PAIR_EMPTY) continue;
         const uint64_t key = tk_pair_key(e);

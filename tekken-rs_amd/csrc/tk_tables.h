@@ -24,7 +24,7 @@ struct TkTablesView {
     const tk_long_entry* long_tab;   // whole pieces of >= 17 bytes
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
-    const uint32_t* pair_filter;     // [TK_FILTER_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab, then the PAIR2 bit map (tk_hash.h)
+    const uint32_t* pair_filter;     // [TK_PAIRF_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab (tk_hash.h)
     const tk_long_entry* key64_tab;  // whole pieces of 17..64 bytes, hashed by dwords (tk_hash.h KEY64): the flat kernel's look-up
     uint32_t key64_mask;
     const uint32_t* uc_bmp;          // [4096] the class trie flattened for the BMP: 16 x 2-bit classes per word, word cp >> 4 (ONE load per char)

@@ -354,9 +354,7 @@ extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_
     out[3] = T.n_key_second; out[4] = T.n_key_spill_slots; out[5] = (uint64_t)T.pair_mask + 1;
     // PAIR filter (tk_hash.h): every stored pair must have its bit set (a clear bit is taken as proof of absence);
     // out[6] = pairs, out[7] = set bits, out[8] = filter bits
-    if (T.pair_filter.size() != TK_FILTER_WORDS) { g_err = "pair filter size"; return TK_ERR_RUNTIME; }
-    for (uint32_t i = 0; i < 65536u; ++i)                    // the PAIR2 bit map behind it says exactly what PAIR2 says
-        if ((((T.pair_filter[TK_PAIRF_WORDS + (i >> 5)] >> (i & 31u)) & 1u) != 0u) != (T.pair2[i] != TK_RANK_MAX)) { g_err = "PAIR2 bit map differs from PAIR2"; return TK_ERR_RUNTIME; }
+    if (T.pair_filter.size() != TK_PAIRF_WORDS) { g_err = "pair filter size"; return TK_ERR_RUNTIME; }
     uint64_t n_pairs = 0, n_set = 0;
     for (uint64_t e : T.pair_tab) {
         if (e == TK_PAIR_EMPTY) continue;
@@ -365,7 +363,7 @@ extern "C" int emu_table_info(const uint8_t* blob, const uint32_t* offs, uint32_
         const uint32_t b = tk_pair_fbit(tk_pair_hash((uint32_t)(key >> TK_ID_BITS), (uint32_t)(key & ((1u << TK_ID_BITS) - 1u))));
         if (b >= (1u << TK_PAIRF_LOG2) || !((T.pair_filter[b >> 5] >> (b & 31u)) & 1u)) { g_err = "a stored pair is missing from the PAIR filter"; return TK_ERR_RUNTIME; }
     }
-    for (uint32_t i = 0; i < TK_PAIRF_WORDS; ++i) n_set += (uint64_t)__builtin_popcount(T.pair_filter[i]);
+    for (uint32_t w : T.pair_filter) n_set += (uint64_t)__builtin_popcount(w);
     if (n_pairs != T.n_pairs || n_set > n_pairs) { g_err = "pair filter counts"; return TK_ERR_RUNTIME; }
     out[6] = n_pairs; out[7] = n_set; out[8] = 1ull << TK_PAIRF_LOG2;
     return TK_OK;

@@ -464,9 +464,12 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     if (a.cut_list && a.pattern == 0) {
-        // the chunks with a piece of more than 64 bytes (none on ordinary text: the blocks read a zero and leave)
-        if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_cut_split_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(tk_flat_cut_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+        // the chunks with a piece of more than 64 bytes (none on ordinary text: the blocks read a zero and leave -- two blocks
+        // per CU, not the seven of the flat kernel: dispatching 1 792 blocks that do nothing took 10 us of every C2 step; the
+        // 14 k listed regions of the 4 M-document Zipf shape are seven per wave instead of two)
+        const uint64_t cblocks = blocks > cap / 7 * 2 && cap >= 7 ? cap / 7 * 2 : blocks;
+        if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_cut_split_kernel, dim3((uint32_t)cblocks), dim3(TKF_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(tk_flat_cut_kernel, dim3((uint32_t)cblocks), dim3(TKF_BLOCK), 0, s, a);
     }
     return hipGetLastError();
 }

@@ -122,7 +122,6 @@ struct tk_ctx {
     DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
     DevBuf t_inline, t_len8;   // decode: 16-byte inline entries and one-byte lengths by rank (built at the first decode call)
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
-    TkScanChain scan;                                   // tk_launch_scan's state lives in block_sums (all scans of a context run on its stream, one after the other)
     DevBuf f_long;             // flat path: records of the pieces of 65..TKF_LONGCAP bytes
     DevBuf long_jobs;              // tk_long.hip: the long pieces of the long-list documents
     DevBuf long_list;              // pass 2 -> tk_long.hip: documents with a long piece that is not a vocabulary key
@@ -342,13 +341,6 @@ const TkHostTables* tk_ctx_host_tables(const tk_ctx* c) { return c ? &c->host : 
 
 // Pass 2 over the n_def documents of c->defer_list: documents with a long piece that missed the vocabulary need the
 // scratch-backed cooperative merge.  The scratch is sized from the longest deferred document.
-// tk_launch_scan's workspace: the context's block_sums buffer (ceil(n / 2048) + 2 words), with the host-side state that goes with it
-static TkScanChain* scan_chain(tk_ctx* c) {
-    c->scan.state = (uint64_t*)c->block_sums.p;
-    c->scan.bytes = c->block_sums.cap;
-    return &c->scan;
-}
-
 static int run_pass2(tk_ctx* c, TkEncodeArgs& a, const uint64_t* d_offs, uint32_t n_def, hipStream_t s, uint64_t max_waves = 1024) {
     const bool dbg = getenv("TK_DEBUG_LOG") != nullptr;
     uint32_t maxlen32 = 0;
@@ -527,7 +519,7 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
     uint32_t n_waves = (uint32_t)(want < 8192 ? (want ? want : 1) : 8192);
     TK_HIP(c, tk_launch_encode(a, 0, n_waves, s));
     TK_HIP(c, hipEventRecord(c->ev[1], s));
-    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, scan_chain(c), s));
+    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs,
                                 (uint32_t*)c->out_ids.p, s));
     TK_HIP(c, hipEventRecord(c->ev[2], s));
@@ -542,7 +534,7 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
     if (ctr[1] != 0 && getenv("TK_DEBUG_SKIP_PASS2") == nullptr) {
         int rc2 = run_pass2(c, a, d_offs, ctr[1], s);
         if (rc2 != TK_OK) return rc2;
-        TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, scan_chain(c), s));
+        TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs,
                                     (uint32_t*)c->out_ids.p, s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
@@ -677,13 +669,13 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, hipMemcpyAsync(c->h_pin + 32, ctr, 64, hipMemcpyDeviceToHost, sb));
         TK_HIP(c, hipEventRecord(c->ev_b[1], sb));
     }
-    TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, scan_chain(c), s));
+    TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_merge(fa, s));
     uint64_t total = 0;
     auto finish = [&](int final_pass, bool wait) -> int {
         TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, d_P, fa.lstart, fa.flags, fa.holes, extra,
                                         (uint32_t*)c->counts.p, c->f_info.p, final_pass, ctr + 4, s));
-        TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, scan_chain(c), s));
+        TK_HIP(c, tk_launch_scan((const uint32_t*)c->counts.p, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
         TK_HIP(c, tk_launch_flat_assemble(n_docs, c->f_info.p, fa.kcount, (const uint64_t*)c->out_offs.p, fa.tmp,
                                           (const uint32_t*)c->staging.p, (uint32_t*)c->out_ids.p, c->host.bos_id,
                                           c->host.eos_id, add_bos, add_eos, (uint64_t*)(ctr + 6),
@@ -852,7 +844,7 @@ static int run_pipeline_seq(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
         if (rc != TK_OK) return rc;
     }
     TK_HIP(c, hipEventRecord(c->ev[1], s));
-    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, scan_chain(c), s));
+    TK_HIP(c, tk_launch_scan(a.counts, n_docs, (uint64_t*)c->out_offs.p, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_compact(a.staging, d_offs, a.counts, (const uint64_t*)c->out_offs.p, n_docs, (uint32_t*)c->out_ids.p, s));
     TK_HIP(c, hipEventRecord(c->ev[2], s));
     TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->out_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
@@ -1386,7 +1378,7 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     TK_HIP(c, hipMemsetAsync(c->dec_err.p, 0xFF, 24, s));
     TK_HIP(c, hipEventRecord(c->ev[0], s));
     TK_HIP(c, tk_launch_decode_doclen(a, s));
-    TK_HIP(c, tk_launch_scan(a.lens, n_docs, (uint64_t*)c->dec_offs.p, scan_chain(c), s));
+    TK_HIP(c, tk_launch_scan(a.lens, n_docs, (uint64_t*)c->dec_offs.p, (uint64_t*)c->block_sums.p, s));
     uint64_t total = 0;
     unsigned long long err[3] = {~0ull, ~0ull, ~0ull};
     TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));

@@ -26,17 +26,9 @@ hipError_t tk_launch_small(const TkEncodeArgs& args, uint32_t* out_ids, uint64_t
 hipError_t tk_launch_encode_long(const TkEncodeArgs& args, uint32_t n_walk_waves, uint32_t n_merge_blocks, hipStream_t s);
 hipError_t tk_launch_encode_long_merge(const TkEncodeArgs& args, uint32_t n_merge_blocks, uint32_t n_compact_blocks, hipStream_t s);
 
-// counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum) in ONE kernel (chained tiles, decoupled look-back); the chain's
-// device buffer holds ceil(n/2048)+2 u64.  offs[n] (= total) is also what the host reads back.  Sums stay below 2^40.
-// the scan state of a context: device words (ticket counter + one status word per tile) and what the host knows about them
-struct TkScanChain {
-    uint64_t* state = nullptr;   // device buffer
-    size_t bytes = 0;            // its size
-    const void* zeroed = nullptr;   // the buffer that has been cleared (a re-allocated one is cleared before its first use) ...
-    size_t zeroed_bytes = 0;        // ... and its size then (a buffer only ever grows: same address, other size = another buffer)
-    uint32_t epoch = 0, ticket = 0;
-};
-hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, TkScanChain* chain, hipStream_t s);
+// counts[n] (u32) -> offs[n+1] (u64, exclusive prefix sum); block_sums: workspace of
+// ceil(n/2048)+1 u64.  offs[n] (= total) is also what the host reads back.
+hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s);
 
 // out_ids[out_offs[d] + k] = staging[doc_offs[d] + 2*d + k] for k < counts[d]
 hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, const uint32_t* counts,

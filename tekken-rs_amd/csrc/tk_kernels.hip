@@ -126,31 +126,36 @@ __device__ __forceinline__ uint64_t tk_block_exclusive_scan(uint64_t v, uint64_t
     return base + x - v;
 }
 
-// ONE kernel per scan (the three-kernel form -- block sums, their scan by one block, apply -- cost two more launches and two
-// more passes of launch latency, twice per batch: ~25 us of a 1.28 ms C2 step): tiles of 2048 counts, every block takes a
-// ticket for its tile (a block therefore only ever waits for tiles that are already running), publishes its aggregate, looks
-// back over the tiles in front of it with one wave -- 64 status words at a time -- until it meets one that has published its
-// inclusive prefix, and publishes its own ("decoupled look-back").  A status word carries the launch's epoch next to state and
-// value: nothing is cleared between launches, stale words read as "not ready".
-//   state[0] (low 32 bits): the ticket counter, never reset (the host passes the value it has at launch)
-//   state[1 + t]: [epoch : 22 | 0 = not ready, 1 = aggregate, 2 = inclusive prefix : 2 | value : 40]
-#define TKS_VBITS 40
-#define TKS_VMASK ((1ull << TKS_VBITS) - 1ull)
-__device__ __forceinline__ uint64_t tks_load(const uint64_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tks_store(uint64_t* p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ __launch_bounds__(TK_BLOCK) void tk_scan_chained(const uint32_t* __restrict__ counts, uint64_t n, uint64_t* __restrict__ offs,
-                                                            uint64_t* state, uint32_t ticket_base, uint32_t epoch, uint64_t n_tiles) {
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_block_sums(const uint32_t* counts, uint64_t n, uint64_t* block_sums) {
     __shared__ uint64_t lds[TK_BLOCK / 64];
-    __shared__ uint64_t s_bcast;
-    uint64_t* status = state + 1;
-    if (threadIdx.x == 0) s_bcast = (uint64_t)(atomicAdd(reinterpret_cast<uint32_t*>(state), 1u) - ticket_base);
-    __syncthreads();
-    const uint64_t tile = s_bcast;
-    const uint64_t base = tile * TK_SCAN_TILE + (uint64_t)threadIdx.x * TK_SCAN_PER_THREAD;
+    const uint64_t base = (uint64_t)blockIdx.x * TK_SCAN_TILE + (uint64_t)threadIdx.x * TK_SCAN_PER_THREAD;
+    uint64_t v = 0;
+    for (int k = 0; k < TK_SCAN_PER_THREAD; ++k)
+        if (base + k < n) v += counts[base + k];
+    uint64_t tot;
+    (void)tk_block_exclusive_scan(v, lds, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_top(uint64_t* block_sums, uint64_t n_blocks) {
+    // single block: exclusive scan of block_sums in place; total at block_sums[n_blocks]
+    __shared__ uint64_t lds[TK_BLOCK / 64];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n_blocks; base += TK_BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_blocks ? block_sums[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = tk_block_exclusive_scan(v, lds, &tot);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) block_sums[n_blocks] = carry;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void tk_scan_apply(const uint32_t* counts, uint64_t n, const uint64_t* block_sums,
+                                                          uint64_t n_blocks, uint64_t* offs) {
+    __shared__ uint64_t lds[TK_BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * TK_SCAN_TILE + (uint64_t)threadIdx.x * TK_SCAN_PER_THREAD;
     uint32_t c[TK_SCAN_PER_THREAD];
     uint64_t v = 0;
     for (int k = 0; k < TK_SCAN_PER_THREAD; ++k) {
@@ -158,74 +163,23 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_scan_chained(const uint32_t* __re
         v += c[k];
     }
     uint64_t tot;
-    const uint64_t ex = tk_block_exclusive_scan(v, lds, &tot);   // (its barriers also order the read of s_bcast above before the write below)
-    if (threadIdx.x < 64) {
-        const int lane = (int)threadIdx.x;
-        const uint64_t tagA = ((uint64_t)epoch << (TKS_VBITS + 2)) | (1ull << TKS_VBITS), tagP = ((uint64_t)epoch << (TKS_VBITS + 2)) | (2ull << TKS_VBITS);
-        uint64_t run = 0;
-        if (tile != 0) {
-            if (lane == 0) tks_store(status + tile, tagA | (tot & TKS_VMASK));
-            int64_t hi = (int64_t)tile - 1;                  // the window: tiles hi, hi - 1, ..., hi - 63 (lane = distance)
-            for (;;) {
-                const int64_t t = hi - lane;
-                const uint64_t w = t >= 0 ? tks_load(status + t) : tagP;   // in front of tile 0: a prefix of 0
-                const uint32_t st = (uint32_t)(w >> TKS_VBITS) & 3u;
-                const bool ready = (uint32_t)(w >> (TKS_VBITS + 2)) == epoch && st != 0u;
-                const uint64_t R = __ballot(ready), P = __ballot(ready && st == 2u);
-                uint64_t take = 0;                           // lanes whose values are added in this round
-                bool done = false;
-                if (P) {
-                    const int fp = __builtin_ctzll(P);
-                    const uint64_t need = fp == 63 ? ~0ull : ((2ull << fp) - 1ull);
-                    if ((R & need) == need) { take = need; done = true; }
-                } else if (R == ~0ull) {
-                    take = ~0ull;
-                }
-                if (take) {
-                    uint64_t x = ((take >> lane) & 1ull) ? (w & TKS_VMASK) : 0ull;
-                    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-                    run += x;
-                    if (done) break;
-                    hi -= 64;
-                } else {
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-        }
-        if (lane == 0) {
-            tks_store(status + tile, tagP | ((run + tot) & TKS_VMASK));
-            s_bcast = run;
-        }
-    }
-    __syncthreads();
-    uint64_t r = s_bcast + ex;
+    uint64_t run = block_sums[blockIdx.x] + tk_block_exclusive_scan(v, lds, &tot);
     for (int k = 0; k < TK_SCAN_PER_THREAD; ++k) {
-        if (base + k < n) offs[base + k] = r;
-        r += c[k];
+        if (base + k < n) offs[base + k] = run;
+        run += c[k];
     }
-    if (tile + 1 == n_tiles && threadIdx.x == 0) offs[n] = s_bcast + tot;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offs[n] = block_sums[n_blocks];
 }
 
-// chain: the context's scan state (device words + what the host knows about them)
-hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, TkScanChain* chain, hipStream_t s) {
-    const uint64_t n_tiles = (n + TK_SCAN_TILE - 1) / TK_SCAN_TILE;
-    if (n_tiles == 0) {
+hipError_t tk_launch_scan(const uint32_t* counts, uint64_t n, uint64_t* offs, uint64_t* block_sums, hipStream_t s) {
+    const uint64_t n_blocks = (n + TK_SCAN_TILE - 1) / TK_SCAN_TILE;
+    if (n_blocks == 0) {
         return hipMemsetAsync(offs, 0, sizeof(uint64_t), s);
     }
-    if (chain->state == nullptr || (n_tiles + 2) * 8 > chain->bytes) return hipErrorInvalidValue;
-    if (chain->zeroed != chain->state || chain->zeroed_bytes != chain->bytes || chain->epoch >= (1u << 22) - 1u) {
-        // a fresh buffer (or the epoch counter about to wrap): every word 0 = "never written"
-        hipError_t e = hipMemsetAsync(chain->state, 0, chain->bytes, s);
-        if (e != hipSuccess) return e;
-        chain->zeroed = chain->state;
-        chain->zeroed_bytes = chain->bytes;
-        chain->epoch = 0;
-        chain->ticket = 0;
-    }
-    ++chain->epoch;
-    hipLaunchKernelGGL(tk_scan_chained, dim3((uint32_t)n_tiles), dim3(TK_BLOCK), 0, s, counts, n, offs, chain->state, chain->ticket,
-                       chain->epoch, n_tiles);
-    chain->ticket += (uint32_t)n_tiles;                     // (wraps like the device counter)
+    hipLaunchKernelGGL(tk_scan_block_sums, dim3((uint32_t)n_blocks), dim3(TK_BLOCK), 0, s, counts, n, block_sums);
+    hipLaunchKernelGGL(tk_scan_top, dim3(1), dim3(TK_BLOCK), 0, s, block_sums, n_blocks);
+    hipLaunchKernelGGL(tk_scan_apply, dim3((uint32_t)n_blocks), dim3(TK_BLOCK), 0, s, counts, n, block_sums, n_blocks,
+                       offs);
     return hipGetLastError();
 }
 

@@ -136,13 +136,14 @@ TK_DEV uint32_t tk_load_u32_unaligned(const uint8_t* p) {
     typedef uint32_t __attribute__((aligned(1))) u32_u;
     return *reinterpret_cast<const u32_u*>(p);
 }
-TK_DEV uint32_t tk_probe_key64(const TkTablesView& t, const uint32_t* tw, uint32_t sh, uint32_t len) {
-    const uint32_t nd = (len + 3u) >> 2;
+TK_DEV uint32_t tk_probe_key64(const TkTablesView& t, const uint32_t* tw, uint32_t sh, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    // k0..k3: the piece's first 16 bytes (the caller has them in registers: the exact-key probe of the shorter pieces takes them too)
+    const uint32_t nd = (len + 3u) >> 2;                    // 5..16
     const uint32_t tail = (len & 3u) ? ((1u << (8u * (len & 3u))) - 1u) : 0xFFFFFFFFu;
-    uint32_t ha = 0;
+    uint32_t ha = tk_k64_start(k0, k1, k2, k3);
     {
-        uint32_t lo = tw[0];
-        for (uint32_t j = 0; j < nd; ++j) {
+        uint32_t lo = tw[4];
+        for (uint32_t j = 4; j < nd; ++j) {
             const uint32_t hi = tw[j + 1];
             uint32_t w = wv_alignbyte(hi, lo, sh);
             if (j + 1u == nd) w &= tail;
@@ -152,22 +153,30 @@ TK_DEV uint32_t tk_probe_key64(const TkTablesView& t, const uint32_t* tw, uint32
     }
     const uint32_t hb = tk_k64_tag(ha);
     uint32_t s = tk_k64_slot(ha, len) & t.key64_mask;
-    for (uint32_t tries = 0; tries <= t.key64_mask; ++tries) {
-        const tk_u32x4 e = *reinterpret_cast<const tk_u32x4*>(t.key64_tab + s);  // {tag, rank, len, blob_off}
-        if (e.z == 0u) return TK_RANK_MAX;
-        if (((e.z ^ len) | (e.x ^ hb)) == 0u) {
-            const uint8_t* q = t.blob + e.w;                                     // (the blob has 16 bytes of slack behind its last token)
-            uint32_t diff = 0, lo = tw[0];
-            for (uint32_t j = 0; j < nd; ++j) {
-                const uint32_t hi = tw[j + 1];
-                uint32_t w = wv_alignbyte(hi, lo, sh) ^ tk_load_u32_unaligned(q + 4u * j);
-                if (j + 1u == nd) w &= tail;
-                diff |= w;
-                lo = hi;
+    // Two slots per round trip: a piece that is no token (most long pieces of running text) ends at the first EMPTY slot, and with
+    // one slot per trip the wave waited for the longest probe chain among its lanes.
+    for (uint32_t tries = 0; tries <= t.key64_mask; tries += 2) {
+        const uint32_t s1 = (s + 1u) & t.key64_mask;
+        tk_u32x4 e0 = *reinterpret_cast<const tk_u32x4*>(t.key64_tab + s);   // {tag, rank, len, blob_off}
+        tk_u32x4 e1 = *reinterpret_cast<const tk_u32x4*>(t.key64_tab + s1);
+        WV_PIN(e0.x); WV_PIN(e1.x);                         // both loads before the first compare
+        for (int q = 0; q < 2; ++q) {
+            const tk_u32x4 e = q ? e1 : e0;
+            if (e.z == 0u) return TK_RANK_MAX;
+            if (((e.z ^ len) | (e.x ^ hb)) == 0u) {
+                const uint8_t* qb = t.blob + e.w;                                 // (the blob has 16 bytes of slack behind its last token)
+                uint32_t diff = 0, lo = tw[0];
+                for (uint32_t j = 0; j < nd; ++j) {
+                    const uint32_t hi = tw[j + 1];
+                    uint32_t w = wv_alignbyte(hi, lo, sh) ^ tk_load_u32_unaligned(qb + 4u * j);
+                    if (j + 1u == nd) w &= tail;
+                    diff |= w;
+                    lo = hi;
+                }
+                if (diff == 0u) return e.y;
             }
-            if (diff == 0u) return e.y;
         }
-        s = (s + 1u) & t.key64_mask;
+        s = (s + 2u) & t.key64_mask;
     }
     return TK_RANK_MAX;
 }

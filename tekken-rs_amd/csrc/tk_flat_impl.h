@@ -894,12 +894,13 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             kk[2] = wv_alignbyte(t3, t2, sh) & km[2]; kk[3] = wv_alignbyte(t4, t3, sh) & km[3];
         }
         uint32_t r = kk[0];                                 // rank of a single byte is the byte (src/tekkenizer.rs:793-798)
+        uint32_t h = 0;
         if (TKF_ABL(a, 1)) {
             r = 7u;
         } else if (TKF_ABL(a, 64)) {
             r = (kk[0] ^ kk[1] ^ kk[2] ^ kk[3]) & 0xFFFFu;                                            // timing: no hash, no table
         } else {
-            const uint32_t h = tk_key_hash((uint32_t)MODE, kk[0], kk[1], kk[2], kk[3], len);
+            h = tk_key_hash((uint32_t)MODE, kk[0], kk[1], kk[2], kk[3], len);
             if (TKF_ABL(a, 128)) {
                 r = h & 0xFFFFu;                                                                      // timing: no table
             } else if (len - 2u <= 14u) {                   // 2..16 bytes: exact-key probe
@@ -933,8 +934,14 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 else toolong = true;                        // (a fragment whose end the region does not show: no cut in 64 bytes)
             } else if (len > 16u && !TKF_ABL(a, 1) && !(CUT && frag)) {
                 // 17..64 bytes: KEY64, the piece's dwords from the LDS copy of the region (the polynomial byte hash of LONG,
-                // two multiplies and a global load per byte, was 44 % of this kernel on mixed UTF-8 text, whose words are long)
-                r = tk_probe_key64(t, lds + TKF_L_TXT + (pos >> 2), pos & 3u, len);
+                // two multiplies and a global load per byte, was 44 % of this kernel on mixed UTF-8 text, whose words are long).
+                // First the pre-filter: the hash of (first 16 bytes, length) is at hand, and a clear bit says "no token"
+                // without the fold over the piece's dwords and without a probe -- the answer for most long pieces of running text
+                r = TK_RANK_MAX;
+                const uint32_t pb = tk_k64_prebit(h);
+                const uint32_t* pre = reinterpret_cast<const uint32_t*>(t.key64_tab + t.key64_mask + 1u);
+                const bool maybe = TKF_ABL(a, 64) || TKF_ABL(a, 128) || ((pre[pb >> 5] >> (pb & 31u)) & 1u) != 0u;
+                if (maybe) r = tk_probe_key64(t, lds + TKF_L_TXT + (pos >> 2), pos & 3u, len, kk[0], kk[1], kk[2], kk[3]);
             }
             if (toolong) wv_lds_or(lds + TKF_L_BAD + (pos >> TKF_LOGW), 1u << (pos & (TKF_W - 1)));
             if (wv_ballot(lres != 0u)) {

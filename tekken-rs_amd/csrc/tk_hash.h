@@ -105,11 +105,21 @@ TK_HD uint32_t tk_pair_hash(uint32_t a, uint32_t b) {
 TK_HD uint32_t tk_pair_fbit(uint32_t h) { return h >> (32 - TK_PAIRF_LOG2); }
 
 /* KEY64: whole pieces of 17..64 bytes as the FLAT kernel looks them up -- one lane per piece, the bytes as little-endian
-   dwords (the last one zero padded), ONE multiply per dword (the polynomial byte hash of LONG, which the per-document
-   kernels compute with one lane per byte, cost this kernel two multiplies and a dependent load per BYTE).
-   Entries like LONG: {tag, rank, len, blob_off}, linear probing from tk_k64_slot(ha, len), tag = tk_k64_tag(ha), verified
-   against the blob. */
-TK_HD void tk_k64_step(uint32_t& ha, uint32_t w) { ha = (ha ^ w) * 0x9E3779B1u + (ha >> 15); }
+   dwords (the last one zero padded).  The hash folds the dwords with a rotate and an exclusive or each (no multiply: 32-bit
+   multiplies are quarter rate, and on text whose words are long this hash was a third of the flat kernel), starting from the
+   first four dwords -- which the kernel holds in registers anyway --, and is scrambled ONCE at the end (tk_k64_slot / tag).
+   A weak fold only costs false candidates: every tag match is verified against the blob.
+   Entries like LONG: {tag, rank, len, blob_off}, linear probing from tk_k64_slot(ha, len), tag = tk_k64_tag(ha). */
+/* In front of KEY64: one bit per tk_key_hash(first 16 bytes, length) of every token of 17..64 bytes (2^18 bits = 32 KB, stored right
+   behind the table's entries).  The flat kernel has that hash of every piece anyway; a clear bit proves that the piece is no token
+   -- no dword fold, no table probe -- and most long pieces of running text are none. */
+#define TK_K64PRE_LOG2 18
+#define TK_K64PRE_WORDS (1u << (TK_K64PRE_LOG2 - 5))
+TK_HD uint32_t tk_k64_prebit(uint32_t h) { return h >> (32 - TK_K64PRE_LOG2); }
+TK_HD uint32_t tk_k64_start(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    return k0 ^ tk_rotl32(k1, 7) ^ tk_rotl32(k2, 14) ^ tk_rotl32(k3, 21);
+}
+TK_HD void tk_k64_step(uint32_t& ha, uint32_t w) { ha = tk_rotl32(ha, 5) ^ w; }
 TK_HD uint32_t tk_k64_slot(uint32_t ha, uint32_t len) { return tk_fmix32(ha + len * 0x165667B1u); }
 TK_HD uint32_t tk_k64_tag(uint32_t ha) { return tk_fmix32(ha ^ 0x85EBCA77u); }   /* other bits of the same hash: the blob compare decides */
 

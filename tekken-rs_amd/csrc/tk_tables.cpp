@@ -57,7 +57,7 @@ void TkHostTables::make_cut_tables() {
         }
         const uint32_t cap = pow2_at_least(2 * n64 + 1);
         key64_mask = cap - 1;
-        key64_tab.assign(cap, tk_long_entry{0, 0, 0, 0});
+        key64_tab.assign(cap + TK_K64PRE_WORDS / 4, tk_long_entry{0, 0, 0, 0});   // entries, then the pre-filter's bit words (tk_hash.h)
         for (uint32_t r = 0; r < n_ranks; ++r) {
             const uint8_t* p = blob.data() + offs[r];
             const uint32_t len = offs[r + 1] - offs[r];
@@ -66,11 +66,19 @@ void TkHostTables::make_cut_tables() {
             for (uint32_t j = 0; j < len; j += 4) {
                 uint32_t w = 0;
                 for (uint32_t k = 0; k < 4 && j + k < len; ++k) w |= (uint32_t)p[j + k] << (8 * k);
-                tk_k64_step(ha, w);
+                if (j == 0) ha = w;                                       // tk_k64_start, dword by dword
+                else if (j == 4) ha ^= tk_rotl32(w, 7);
+                else if (j == 8) ha ^= tk_rotl32(w, 14);
+                else if (j == 12) ha ^= tk_rotl32(w, 21);
+                else tk_k64_step(ha, w);
             }
             uint32_t sl = tk_k64_slot(ha, len) & key64_mask;
             while (key64_tab[sl].len) sl = (sl + 1) & key64_mask;
             key64_tab[sl] = tk_long_entry{tk_k64_tag(ha), r, len, offs[r]};
+            uint32_t k[4];
+            memcpy(k, p, 16);                                             // (little-endian host, like the byte order of every key here)
+            const uint32_t pb = tk_k64_prebit(tk_key_hash(key_hash_mode, k[0], k[1], k[2], k[3], len));
+            reinterpret_cast<uint32_t*>(key64_tab.data() + cap)[pb >> 5] |= 1u << (pb & 31u);
         }
     }
     cut_k2.assign(TK_CUT_K2_WORDS, 0u);

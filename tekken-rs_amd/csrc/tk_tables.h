@@ -25,7 +25,8 @@ struct TkTablesView {
     const uint64_t* pair_tab;        // (idA,idB) -> rank, packed 21/21/21; cuckoo buckets of 2 entries, pair_mask = buckets - 1
     const uint32_t* pair2;           // [65536] (b0 | b1<<8) -> rank or TK_RANK_MAX
     const uint32_t* pair_filter;     // [TK_PAIRF_WORDS] bit tk_pair_fbit(hash) set for every pair of pair_tab (tk_hash.h)
-    const tk_long_entry* key64_tab;  // whole pieces of 17..64 bytes, hashed by dwords (tk_hash.h KEY64): the flat kernel's look-up
+    const tk_long_entry* key64_tab;  // whole pieces of 17..64 bytes, hashed by dwords (tk_hash.h KEY64): the flat kernel's look-up; behind the
+                                     // key64_mask + 1 entries: TK_K64PRE_WORDS bit words of the pre-filter
     uint32_t key64_mask;
     const uint32_t* uc_bmp;          // [4096] the class trie flattened for the BMP: 16 x 2-bit classes per word, word cp >> 4 (ONE load per char)
     const uint32_t* cut_k2;          // [TK_CUT_K2_WORDS] bit (b0 | b1 << 8): the two bytes are a vocabulary KEY (cut rule, tk_hash.h)

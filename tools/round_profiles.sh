@@ -3,9 +3,11 @@
 # (bench lines for every BASELINE shape, kernel traces + stats, one-step timelines, PMC passes per shape;
 # tools/profile_summary.py <tag> turns gpurun_out/ into the committed files under profiles/)
 tag=${1:-r03}
+part=${2:-all}          # all | profiles (step 1: traces + PMC passes + their summary) | bench (step 2: the bench lines): two calls fit gpurun's 20 minutes each
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd $root
+if [ "$part" != bench ]; then
 # 1. kernel traces and PMC passes first; their summary (profiles/hbm_traffic*.json, stamped with this build's commit) is written on
 #    the box so that the bench lines of step 2 carry traffic and VALU floor measured at the SAME commit
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +28,8 @@ done
 python tools/profile_summary.py ${tag} > $out/profile_summary_${tag}.log 2>&1 || { tail -5 $out/profile_summary_${tag}.log; exit 1; }
 mkdir -p $out/profiles_${tag} && cp profiles/hbm_traffic*.json profiles/${tag}_sq_counters*.json $out/profiles_${tag}/
 echo "PMC summary written"
+fi
+[ "$part" = profiles ] && exit 0
 # 2. the bench lines
 Q="--decode-steps 0 --host-steps 0 --single-docs 0"
 timeout -k 10 300 python bench.py > $out/bench_${tag}_c2.json 2> $out/bench_${tag}_c2.err || exit 1

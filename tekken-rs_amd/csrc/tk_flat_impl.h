@@ -52,6 +52,9 @@
 #define TKF_L_PFX (TKF_L_PS + 64)                   /* [64] pieces before the lane */
 #define TKF_L_BAD (TKF_L_PFX + 64)                  /* [64] positions that make their document fall back */
 #define TKF_L_BPFX (TKF_L_BAD + 64)                 /* [64] bad positions before the lane */
+/* the dealt walk's list of lead-byte positions (step 1, default pattern): u16 entries in the list words behind the class words */
+#define TKF_WALKOFF 192                              /* words */
+#define TKF_WALKCAP (2 * (TKF_LISTCAP / 2 - TKF_WALKOFF))   /* 672 positions; a region with more lead bytes is walked lane by lane */
 #define TKF_L_CL TKF_L_LIST                          /* [3 * 64] classes L, N, S of the multi-byte code points (step 1 only: shares the
                                                         words of the piece list, which is built in step 5) */
 #define TKF_L_KM (TKF_L_BPFX + 64)                  /* [17 * 4] byte masks of a zero-padded key of length 0..16 (filled once per wave) */
@@ -546,7 +549,60 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 if (cls == TK_CLS_N) nmb = true;
             }
         };
-        while (wv_ballot(w != 0u)) {
+        // Default pattern: the lead bytes are dealt out over ALL lanes -- their positions go into an LDS list (the words of the
+        // piece list behind the class words; step 5 builds its list later), one lane per char, 64 chars per round.  The chars
+        // the range rules leave over sit in a few lanes (a Thai word, a run of symbols): with every lane walking its own
+        // bytes the wave ran as many rounds -- each one a table load and its latency -- as its fullest lane had chars.
+        bool dealt = false;
+        if (!PAT) {
+            uint32_t tot;
+            const uint32_t before = tkf_scan_excl((uint32_t)__builtin_popcount(w), lane, &tot);
+            if (tot <= TKF_WALKCAP) {
+                dealt = true;
+                uint16_t* wl = list + 2 * TKF_WALKOFF;
+                uint32_t ww = w, idx = before;
+                while (wv_ballot(ww != 0u)) {
+                    if (ww) {
+                        wl[idx++] = (uint16_t)(TKF_W * lane + __builtin_ctz(ww));
+                        ww &= ww - 1u;
+                    }
+                }
+                wv_lds_sync();
+                for (uint32_t b0 = 0; b0 < tot; b0 += 64u) {
+                    const uint32_t i = b0 + (uint32_t)lane;
+                    if (i < tot) {
+                        const uint32_t p = wl[i];
+                        const uint32_t* tw = lds + TKF_L_TXT + (p >> 2);
+                        const uint32_t v4 = wv_alignbyte(tw[1], tw[0], p & 3u);
+                        const uint32_t b0b = v4 & 0xFFu, b1 = (v4 >> 8) & 0xFFu, b2 = (v4 >> 16) & 0xFFu, b3 = v4 >> 24;
+                        uint32_t cp = 0xFFFFFFFFu, clen = 1;
+                        if (b0b < 0xE0u) {
+                            if ((b1 & 0xC0u) == 0x80u) { cp = ((b0b & 0x1Fu) << 6) | (b1 & 0x3Fu); clen = 2; }
+                        } else if (b0b < 0xF0u) {
+                            if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u) {
+                                cp = ((b0b & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); clen = 3;
+                            }
+                        } else if (b0b < 0xF8u) {
+                            if ((b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && (b3 & 0xC0u) == 0x80u) {
+                                cp = ((b0b & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu); clen = 4;
+                            }
+                        }
+                        const uint32_t q = cp < 0x10000u ? cp : 0u;
+                        uint32_t cw = t.uc_bmp[q >> 4];
+                        uint32_t cls = (cw >> (2u * (q & 15u))) & 3u;
+                        if (cp >= 0x10000u) cls = cp == 0xFFFFFFFFu ? (uint32_t)TK_CLS_O : tk_uc_class(t, cp);
+                        if (cls != TK_CLS_O) {
+                            const uint32_t wi = p >> TKF_LOGW, sh = p & (TKF_W - 1);
+                            const uint64_t bits = (uint64_t)((1u << clen) - 1u) << sh;   // may reach into the next lane's word
+                            wv_lds_or(cl + (cls - 1u) * 64u + wi, (uint32_t)(bits & TKF_WM));
+                            if ((bits >> TKF_W) && wi < 63u) wv_lds_or(cl + (cls - 1u) * 64u + wi + 1u, (uint32_t)(bits >> TKF_W));
+                            if (cls == TK_CLS_N) nmb = true;
+                        }
+                    }
+                }
+            }
+        }
+        while (!dealt && wv_ballot(w != 0u)) {
             if (w) {
                 if (PAT) {
                     const int i = __builtin_ctz(w);

@@ -201,6 +201,7 @@ def main():
 
     enc_ms = []
     pipe_ms = []
+    merge_ms = []
     n_ids_local = 0
     gathered = None
     # N > 1: the link into rank 0 bounds the job.  The ids travel in the 18-bit wire format when the
@@ -245,6 +246,7 @@ def main():
         t = eng.last_timing()
         enc_ms.append(t["encode_kernel_ms"])
         pipe_ms.append(t["pipeline_ms"])
+        merge_ms.append(t.get("merge_ms", 0.0))
         if distributed:
             ids = torch.as_tensor(v_ids, device="cuda")
             oo = torch.as_tensor(v_oo, device="cuda")
@@ -265,6 +267,7 @@ def main():
     torch.cuda.synchronize()
     enc_ms.clear()
     pipe_ms.clear()
+    merge_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         v_ids, v_oo = step()
@@ -350,6 +353,10 @@ def main():
             "roofline": dict({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                               "kernel": "tk_flat_kernel", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+                              # (the span from the end of that kernel to the end of both merge kernels, scans included: on text with many pieces
+                              # outside the vocabulary -- configs[2] -- the merge kernels are the longest part of a step)
+                              "merge_kernels_ms": round(float(np.mean(merge_ms)), 4) if merge_ms else None,
+                              "longest_part": "tk_flat_kernel" if not merge_ms or k_ms >= float(np.mean(merge_ms)) else "tk_merge_kernel + tk_merge_wide_kernel",
                               "pipeline_ms": round(float(np.mean(pipe_ms)), 4),
                               "pipeline_frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                               "bound_by": bound_by}, **traffic_info),

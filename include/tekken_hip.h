@@ -208,6 +208,9 @@ int tk_node_last_timing(const tk_node* node, float* kernels_ms_max, float* gathe
 /* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */
 int tk_last_timing(const tk_ctx* ctx, float* pipeline_ms, float* encode_kernel_ms);
+/* ... and the span from the end of that kernel to the end of the merge kernels (the scans in between included): on text with
+ * many pieces outside the vocabulary (BASELINE configs[2]) the merge kernels, not the encode kernel, are the longest part. */
+float tk_last_merge_ms(const tk_ctx* ctx);
 
 /* Counters of the last call: documents handled by the long-piece path (pass 2), and documents the flat
  * chunk-per-wave kernel handed back to the per-document kernels (non-ASCII, very long runs / pieces). */

@@ -148,6 +148,8 @@ def lib():
     L.tk_tokenizer_decode_batch.restype = ctypes.c_int
     L.tk_tokenizer_decode_batch.argtypes = [vp, u32p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_TextResult), u64p]
     L.tk_last_timing.restype = ctypes.c_int
+    L.tk_last_merge_ms.restype = ctypes.c_float
+    L.tk_last_merge_ms.argtypes = [vp]
     L.tk_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.tk_last_stats.restype = ctypes.c_int
     L.tk_last_stats.argtypes = [vp, u64p, u64p]
@@ -443,7 +445,7 @@ class Engine:
     def last_timing(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().tk_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
-        return {"pipeline_ms": a.value, "encode_kernel_ms": b.value}
+        return {"pipeline_ms": a.value, "encode_kernel_ms": b.value, "merge_ms": float(lib().tk_last_merge_ms(self._h))}
 
     def last_stats(self):
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -139,7 +139,7 @@ struct tk_ctx {
     uint32_t long_ctl_cap = 0;
     bool no_flat_long128 = false;  // TK_FLAT_LONG128=0: every long-piece record takes the single-wave merge
     bool no_flat_long = false;     // TK_FLAT_LONG=0: such pieces hand their documents back (the round-1 behaviour; A / B and tests)
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [4]: behind the merge kernels (tk_last_merge_ms)
     // the tail of a batch (documents handed back by the flat kernel) runs on a second stream beside the merge kernels
     hipStream_t stream_b = nullptr;
     hipEvent_t ev_b[3] = {nullptr, nullptr, nullptr};   // flat kernel done (A) | list of handed-back documents on the host (B) | tail done (B)
@@ -147,7 +147,7 @@ struct tk_ctx {
     DevBuf f_late;                 // documents a long-piece record flagged after the list of handed-back documents was made
     bool serial_tail = false;      // TK_TAIL=serial: the tail behind the merge kernels on the one stream (A / B, tests)
     uint32_t host_syncs = 0;       // host waits of the last flat-pipeline call (diagnostics)
-    float pipeline_ms = 0.f, encode_ms = 0.f;
+    float pipeline_ms = 0.f, encode_ms = 0.f, merge_ms = 0.f;
     uint64_t n_long_docs = 0;
     uint32_t* dbg_mark = nullptr;  // pinned host memory, only with TK_DEBUG_MARKS
     uint32_t* h_pin = nullptr;     // pinned host words: the per-batch device counters land here with ONE copy
@@ -220,7 +220,7 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
         c->err = "hipStreamCreate failed";
         return fail(TK_ERR_RUNTIME);
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
     if (hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TK_ERR_RUNTIME); }
     for (int i = 0; i < 3; ++i)
@@ -303,7 +303,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
                       &c->scratch, &c->long_list, &c->long_jobs, &c->f_long, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 3; ++i)
         if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
@@ -671,6 +671,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     }
     TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
     TK_HIP(c, tk_launch_merge(fa, s));
+    TK_HIP(c, hipEventRecord(c->ev[4], s));
     uint64_t total = 0;
     auto finish = [&](int final_pass, bool wait) -> int {
         TK_HIP(c, tk_launch_flat_counts(d_offs, n_docs, n_bytes, n_chunks, d_P, fa.lstart, fa.flags, fa.holes, extra,
@@ -803,6 +804,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     }
     (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[3], c->ev[2]);
+    (void)hipEventElapsedTime(&c->merge_ms, c->ev[1], c->ev[4]);
     *n_ids = total;
     return TK_OK;
 }
@@ -1253,6 +1255,8 @@ extern "C" void tk_free_result(tk_result* r) {
 }
 
 extern "C" const uint32_t* tk_debug_marks(const tk_ctx* c) { return c ? c->dbg_mark : nullptr; }
+
+extern "C" float tk_last_merge_ms(const tk_ctx* c) { return c ? c->merge_ms : 0.f; }
 
 extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode_kernel_ms) {
     if (!c) return TK_ERR_INVALID_ARG;

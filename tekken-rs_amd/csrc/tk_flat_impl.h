@@ -935,9 +935,18 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // without a piece takes position 0, length 1 -- and only the table loads are predicated.
         const uint32_t idx = j * 64u + (uint32_t)lane;
         const bool act = idx < np_own;
-        const uint32_t p0 = list[idx < np_all ? idx : np_all], p1 = list[idx < np_all ? idx + 1 : np_all];   // (never past the sentinel)
-        const uint32_t pos = act ? p0 : 0u;
-        const uint32_t len = act ? p1 - p0 : 1u;
+        uint32_t pos, len;
+        if (j + 1u < nbatch) {
+            // every batch but the last one: all 64 lanes own a piece and idx + 1 is inside the list -- no clamping, no selects
+            // (a scalar branch; six instructions less per batch)
+            const uint32_t p0 = list[idx], p1 = list[idx + 1u];
+            pos = p0;
+            len = p1 - p0;
+        } else {
+            const uint32_t p0 = list[idx < np_all ? idx : np_all], p1 = list[idx < np_all ? idx + 1 : np_all];   // (never past the sentinel)
+            pos = act ? p0 : 0u;
+            len = act ? p1 - p0 : 1u;
+        }
         // the piece's first 16 bytes from the LDS copy of the region (five aligned dwords, funnel-shifted), zeroed past the
         // piece (masks by length from LDS)
         uint32_t kk[4];

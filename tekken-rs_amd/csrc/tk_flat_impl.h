@@ -1487,7 +1487,16 @@ TK_DEV void tk_merge_holes(const TkFlatArgs& a, bool have, uint32_t holes, uint3
         if (have) {
             d = a.first_doc[chunk];
             d = d > 0 ? d - 1 : 0;
-            while (d + 1 < a.n_docs && (int64_t)a.doc_offs[d + 1] <= g) ++d;
+            // four offsets per round trip (one at a time this was a chain of up to four dependent loads per lane on 512-byte
+            // documents -- a tenth of the merge kernel there); doc_offs[n_docs] = n_bytes > g ends the search by itself
+            for (;;) {
+                const uint64_t i1 = d + 1 < a.n_docs ? d + 1 : a.n_docs, i2 = d + 2 < a.n_docs ? d + 2 : a.n_docs;
+                const uint64_t i3 = d + 3 < a.n_docs ? d + 3 : a.n_docs, i4 = d + 4 < a.n_docs ? d + 4 : a.n_docs;
+                uint64_t o1 = a.doc_offs[i1], o2 = a.doc_offs[i2], o3 = a.doc_offs[i3], o4 = a.doc_offs[i4];
+                const uint32_t cnt = ((int64_t)o1 <= g ? 1u : 0u) + ((int64_t)o2 <= g ? 1u : 0u) + ((int64_t)o3 <= g ? 1u : 0u) + ((int64_t)o4 <= g ? 1u : 0u);
+                d += cnt;                                   // (the offsets do not decrease: the count is the number of steps)
+                if (cnt < 4u) break;
+            }
         }
         const uint32_t key = have ? (uint32_t)d : 0xFFFFFFFFu;             // (documents are numbered below 2^32 - 1)
         const uint32_t kprev = wv_shfl(key, lane > 0 ? lane - 1 : 0), knext = wv_shfl(key, lane < 63 ? lane + 1 : 63);

@@ -596,6 +596,38 @@ void tk_oracle_miss_stats(const tk_oracle* o, const uint8_t* bytes, const uint64
     free(scratch); free(tmp);
 }
 
+/* One record per missed piece (for the analyses of tools/miss_analysis.py: memo hit rates, hole reservations): rec[3 i] = FNV-1a
+   64 of the piece's bytes folded to 32 bits ^ its upper half, rec[3 i + 1] = bytes, rec[3 i + 2] = ids it produces.  Returns the
+   number of missed pieces (only cap records are written). */
+uint64_t tk_oracle_miss_records(const tk_oracle* o, const uint8_t* bytes, const uint64_t* offs, uint64_t n_docs, uint32_t* rec, uint64_t cap) {
+    part_t* scratch = NULL; size_t sc = 0;
+    uint32_t* tmp = NULL; size_t tcap = 0;
+    uint64_t nrec = 0;
+    for (uint64_t d = 0; d < n_docs; ++d) {
+        const uint8_t* text = bytes + offs[d];
+        const size_t n = (size_t)(offs[d + 1] - offs[d]);
+        size_t pos = 0;
+        while (pos < n) {
+            size_t end = o->pattern ? match2_at(text, n, pos) : match_at(text, n, pos);
+            if (rank_of(o, text + pos, end - pos) == RANK_MAX) {
+                if (end - pos > tcap) { tcap = 2 * (end - pos); tmp = (uint32_t*)realloc(tmp, tcap * sizeof(uint32_t)); }
+                const size_t k = bpe_piece(o, text + pos, end - pos, tmp, tcap, 0, &scratch, &sc);
+                if (nrec < cap) {
+                    uint64_t h = 1469598103934665603ull;
+                    for (size_t i = pos; i < end; ++i) { h ^= text[i]; h *= 1099511628211ull; }
+                    rec[3 * nrec] = (uint32_t)h ^ (uint32_t)(h >> 32);
+                    rec[3 * nrec + 1] = (uint32_t)(end - pos);
+                    rec[3 * nrec + 2] = (uint32_t)k;
+                }
+                ++nrec;
+            }
+            pos = end;
+        }
+    }
+    free(scratch); free(tmp);
+    return nrec;
+}
+
 uint64_t tk_oracle_fnv1a(const uint32_t* ids, uint64_t n) {
     uint64_t h = 1469598103934665603ull;
     for (uint64_t i = 0; i < n; ++i) {

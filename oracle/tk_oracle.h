@@ -64,6 +64,9 @@ double tk_oracle_last_batch_seconds(void);
 /* out[4] = {pieces, pieces that miss the vocabulary, bytes of those, ids they produce} over a packed batch. */
 void tk_oracle_miss_stats(const tk_oracle* o, const uint8_t* bytes, const uint64_t* offs, uint64_t n_docs, uint64_t* out);
 
+/* one record {hash32 of the bytes, bytes, ids} per missed piece, for tools/miss_analysis.py; returns their number */
+uint64_t tk_oracle_miss_records(const tk_oracle* o, const uint8_t* bytes, const uint64_t* offs, uint64_t n_docs, uint32_t* rec, uint64_t cap);
+
 /* 2-bit class of a code point: 0=O 1=L 2=N 3=S (tables generated from Python `regex`). */
 int tk_oracle_class(uint32_t cp);
 

@@ -124,6 +124,18 @@ class Oracle:
         lib().tk_oracle_miss_stats(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1, _p(out, ctypes.c_uint64))
         return {"pieces": int(out[0]), "missed": int(out[1]), "missed_bytes": int(out[2]), "missed_ids": int(out[3])}
 
+    def miss_records(self, data: np.ndarray, offs: np.ndarray, cap=1 << 24):
+        """uint32[n, 3] = {hash of the bytes, bytes, ids produced} of every piece that is no vocabulary key (tools/miss_analysis.py)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        rec = np.zeros((cap, 3), np.uint32)
+        dbuf = data if len(data) else np.zeros(1, np.uint8)
+        f = lib().tk_oracle_miss_records
+        f.restype = ctypes.c_uint64
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+        n = f(self._h, dbuf.ctypes.data, offs.ctypes.data, len(offs) - 1, rec.ctypes.data, cap)
+        return rec[:min(int(n), cap)]
+
     def encode_batch(self, data: np.ndarray, offs: np.ndarray, add_bos=True, add_eos=True, threads=1):
         """data: uint8[n_bytes], offs: uint64[D+1] -> (ids uint32[T], out_offs uint64[D+1])."""
         data = np.ascontiguousarray(data, dtype=np.uint8)

@@ -106,6 +106,22 @@ uint64_t tk_cut_chunks(const tk_ctx* ctx);
  * (diagnostics / tests; TK_TAIL=serial at context creation runs the tail behind the merge kernels on the one stream). */
 uint64_t tk_last_host_syncs(const tk_ctx* ctx);
 
+/* Memo of merged pieces (no reference equivalent; `encode` is a pure function of the text, src/tekkenizer.rs:384-386, and stays
+ * one): a device table {piece of 2..16 bytes that is no vocabulary key -> the <= 4 ids the byte-pair merge gives it}, read by the
+ * split + look-up kernel, filled behind the merge kernel, visible from the NEXT call on the context.  Text repeats its unknown
+ * words; a hit costs one 32-byte gather instead of a chain of ~20 dependent PAIR probes.  An entry holds the exact key and the
+ * exact result: the table can change how long a call takes, never an id (tests/test_gpu_parity.py::test_memo_*).
+ *   log2_entries  0 = off (the table is freed); 10..26: 2^n entries of 32 bytes (default 22 = 128 MB, plus a quarter of that for the log of a call's new entries; TK_MEMO_LOG2)
+ *   policy        0 = adaptive: after two calls in a row that hit less than once per 160 bytes of text or less than three times in
+ *                 ten look-ups (text with few unknown pieces, or whose unknown pieces never come back) the table is left
+ *                 alone for 30 calls, 1 = always on (TK_MEMO_POLICY=always)
+ * tk_ctx_memo_clear empties the table.  tk_memo_stats: look-ups (pieces of 2..16 bytes that missed the vocabulary) and hits of
+ * the last call and since the context was created, and whether the last call used the table. */
+int tk_ctx_set_memo(tk_ctx* ctx, int log2_entries, int policy);
+int tk_ctx_memo_clear(tk_ctx* ctx);
+int tk_memo_stats(const tk_ctx* ctx, uint64_t* lookups_last, uint64_t* hits_last, uint64_t* lookups_total, uint64_t* hits_total,
+                  int* active_last);
+
 /* Opt-in: honour the `pattern` of Mistral's tekken.json -- case-aware words
  * (`HelloWorld` -> `Hello`, `World`), single digits, `/` absorbed after punctuation; literal in reference
  * tests/test_small_vocab.rs:62 -- instead of the pattern the reference hard-codes and always uses
@@ -131,13 +147,23 @@ int tk_encode_batch_pipelined(tk_ctx* ctx, const uint8_t* bytes, const uint64_t*
 
 /* Same computation with inputs already resident in HBM (hipMalloc'ed on the context's device):
  * d_bytes = n_bytes packed text bytes, d_doc_offsets = n_docs+1 uint64 (non-decreasing, [0] = 0, [n_docs] = n_bytes:
- * not checked on this entry).  Work is enqueued on
+ * not checked on this entry -- tk_encode_batch_device_ex checks).  Work is enqueued on
  * `hip_stream` (a hipStream_t; NULL = HIP's null stream, so the work is ordered after whatever the
  * caller already enqueued there) and the call returns after the stream has drained.  *d_ids / *d_out_offsets are device buffers owned by the context, valid
  * until the next call on it; *n_ids = total ids. */
 int tk_encode_batch_device(tk_ctx* ctx, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
                            uint64_t n_bytes, int add_bos, int add_eos, void* hip_stream, void** d_ids,
                            void** d_out_offsets, uint64_t* n_ids);
+
+/* The same with the checks tk_encode_batch makes for host callers, on the device (one small kernel and one host wait each, before
+ * anything else runs): TK_CHECK_OFFSETS -- d_doc_offsets[0] == 0, non-decreasing, [n_docs] == n_bytes, else TK_ERR_INVALID_ARG;
+ * TK_CHECK_UTF8 -- every document is well-formed UTF-8 on its own (a Rust &str always is; this includes "no document starts inside
+ * a code point"), else TK_ERR_INVALID_UTF8; implies the offsets check.  checks = 0 is tk_encode_batch_device. */
+#define TK_CHECK_OFFSETS 1
+#define TK_CHECK_UTF8 2
+int tk_encode_batch_device_ex(tk_ctx* ctx, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs, uint64_t n_bytes,
+                              int add_bos, int add_eos, int checks, void* hip_stream, void** d_ids, void** d_out_offsets,
+                              uint64_t* n_ids);
 
 /* ---- decode: batch form of Tekkenizer::decode (src/tekkenizer.rs:436-560) ----
  * The engine needs the special-token strings for TK_POLICY_KEEP: entry i is the string of the special token

@@ -21,10 +21,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtekken_hip.so")
+# (TK_HIP_LIB: another build of the same library -- the development build with the timing ablations, `make ablate`, or an A / B
+# variant --, so that no tool ever has to copy a variant over the shipped file)
+LIB_PATH = os.environ.get("TK_HIP_LIB") or os.path.join(_HERE, "libtekken_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 TK_OK = 0
+CHECK_OFFSETS, CHECK_UTF8 = 1, 2   # tk_encode_batch_device_ex
 TK_ERR_INVALID_CONFIG = -1
 TK_ERR_RUNTIME = -2
 TK_ERR_INVALID_UTF8 = -3
@@ -112,6 +115,13 @@ def lib():
     L.tk_round_path_docs.argtypes = [vp]
     L.tk_long_piece_records.restype = ctypes.c_uint64
     L.tk_long_piece_records.argtypes = [vp]
+    if hasattr(L, "tk_ctx_set_memo"):   # (memo of merged pieces: libraries built before it have neither)
+        L.tk_ctx_set_memo.restype = ctypes.c_int
+        L.tk_ctx_set_memo.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.tk_ctx_memo_clear.restype = ctypes.c_int
+        L.tk_ctx_memo_clear.argtypes = [vp]
+        L.tk_memo_stats.restype = ctypes.c_int
+        L.tk_memo_stats.argtypes = [vp, u64p, u64p, u64p, u64p, ctypes.POINTER(ctypes.c_int)]
     if hasattr(L, "tk_last_host_syncs"):
         L.tk_last_host_syncs.restype = ctypes.c_uint64
         L.tk_last_host_syncs.argtypes = [vp]
@@ -121,6 +131,9 @@ def lib():
     L.tk_encode_batch_device.restype = ctypes.c_int
     L.tk_encode_batch_device.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, vp,
                                          ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    L.tk_encode_batch_device_ex.restype = ctypes.c_int
+    L.tk_encode_batch_device_ex.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp,
+                                            ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     L.tk_host_alloc.restype = ctypes.c_void_p
     L.tk_host_alloc.argtypes = [ctypes.c_size_t]
     L.tk_host_free.argtypes = [ctypes.c_void_p]
@@ -341,6 +354,27 @@ class Engine:
         """Pieces of 65..256 bytes of the last batch that stayed on the flat path as records."""
         return int(lib().tk_long_piece_records(self._h))
 
+    def set_memo(self, log2_entries, policy=0):
+        """Memo of merged pieces (tk_ctx_set_memo): 0 = off, 10..26 = 2^n entries; policy 0 adaptive, 1 always on."""
+        rc = lib().tk_ctx_set_memo(self._h, int(log2_entries), int(policy))
+        if rc != TK_OK:
+            raise self._err(rc)
+
+    def memo_clear(self):
+        rc = lib().tk_ctx_memo_clear(self._h)
+        if rc != TK_OK:
+            raise self._err(rc)
+
+    def memo_stats(self):
+        """{lookups_last, hits_last, lookups_total, hits_total, active_last} (tk_memo_stats)."""
+        if not hasattr(lib(), "tk_memo_stats"):
+            return {"lookups_last": 0, "hits_last": 0, "lookups_total": 0, "hits_total": 0, "active_last": False}
+        v = [ctypes.c_uint64(0) for _ in range(4)]
+        act = ctypes.c_int(0)
+        lib().tk_memo_stats(self._h, *[ctypes.byref(x) for x in v], ctypes.byref(act))
+        return {"lookups_last": v[0].value, "hits_last": v[1].value, "lookups_total": v[2].value, "hits_total": v[3].value,
+                "active_last": bool(act.value)}
+
     def cut_chunks(self):
         """Regions of the last batch whose long pieces were cut into independently merged fragments."""
         return int(lib().tk_cut_chunks(self._h)) if hasattr(lib(), "tk_cut_chunks") else 0
@@ -358,13 +392,19 @@ class Engine:
         ids, oo = self.encode_batch(data, offs, add_bos, add_eos, validate_utf8)
         return [ids[int(oo[d]):int(oo[d + 1])].tolist() for d in range(len(docs))]
 
-    def encode_batch_device(self, d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos=True, add_eos=True, stream=0):
+    def encode_batch_device(self, d_bytes_ptr, d_offs_ptr, n_docs, n_bytes, add_bos=True, add_eos=True, stream=0, checks=0):
         """Inputs resident in HBM (raw device pointers).  Returns (d_ids_ptr, d_out_offs_ptr, n_ids);
-        the output buffers belong to the context and stay valid until the next call."""
+        the output buffers belong to the context and stay valid until the next call.  checks: CHECK_OFFSETS | CHECK_UTF8
+        (tk_encode_batch_device_ex: the offsets / the documents are checked on the device first)."""
         d_ids, d_oo, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0)
-        rc = lib().tk_encode_batch_device(self._h, ctypes.c_void_p(d_bytes_ptr), ctypes.c_void_p(d_offs_ptr), n_docs,
-                                          n_bytes, int(add_bos), int(add_eos), ctypes.c_void_p(stream),
-                                          ctypes.byref(d_ids), ctypes.byref(d_oo), ctypes.byref(n))
+        if checks:
+            rc = lib().tk_encode_batch_device_ex(self._h, ctypes.c_void_p(d_bytes_ptr), ctypes.c_void_p(d_offs_ptr), n_docs,
+                                                 n_bytes, int(add_bos), int(add_eos), int(checks), ctypes.c_void_p(stream),
+                                                 ctypes.byref(d_ids), ctypes.byref(d_oo), ctypes.byref(n))
+        else:
+            rc = lib().tk_encode_batch_device(self._h, ctypes.c_void_p(d_bytes_ptr), ctypes.c_void_p(d_offs_ptr), n_docs,
+                                              n_bytes, int(add_bos), int(add_eos), ctypes.c_void_p(stream),
+                                              ctypes.byref(d_ids), ctypes.byref(d_oo), ctypes.byref(n))
         if rc != TK_OK:
             raise self._err(rc)
         return d_ids.value, d_oo.value, int(n.value)

@@ -165,6 +165,15 @@ struct tk_ctx {
     DevBuf s_offs;
     uint64_t n_small_calls = 0;    // calls served by the one-launch path (tk_last_stats_ex)
     bool small_ready = false;      // small_prepare() went through completely
+    // memo of merged pieces (tk_hash.h MEMO; include/tekken_hip.h tk_ctx_set_memo)
+    DevBuf t_memo, t_memo_log;
+    uint32_t memo_log2 = 22;       // entries = 2^memo_log2 (32 bytes each), 0 = off; TK_MEMO_LOG2
+    uint32_t memo_have_log2 = 0;   // size of the table that is allocated (0: none yet)
+    uint32_t memo_epoch = 0;       // calls that used the table so far
+    int memo_policy = 0;           // 0 adaptive (pause while the hit rate is low), 1 always on; TK_MEMO_POLICY=always
+    uint32_t memo_low_streak = 0, memo_pause = 0;
+    bool memo_active_last = false;
+    uint64_t memo_hits_last = 0, memo_lookups_last = 0, memo_hits_total = 0, memo_lookups_total = 0;
 };
 
 #define TK_SMALL_IDS_CAP (TK_SMALL_MAX_BYTES + 2 * TK_SMALL_MAX_DOCS)
@@ -287,6 +296,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     if (const char* lm = getenv("TK_LONG_MIN")) c->long_min = (uint32_t)atoi(lm);
     if (const char* lz = getenv("TK_LONG_LAZY_MUL")) c->long_lazy_mul = (uint32_t)atoi(lz);
     if (const char* lf = getenv("TK_LONG_FORCE")) c->long_force = (uint32_t)atoi(lf);   // tests: 1 = every long piece through the compacting rounds, 2 = through the lazy rounds
+    if (const char* ml = getenv("TK_MEMO_LOG2")) { const int v = atoi(ml); c->memo_log2 = v <= 0 ? 0u : (uint32_t)(v < 10 ? 10 : v > 26 ? 26 : v); }
+    if (const char* mp = getenv("TK_MEMO_POLICY")) c->memo_policy = strcmp(mp, "always") == 0 ? 1 : 0;
     if (const char* pl = getenv("TK_PIPELINE"))  // "doc": per-document kernels only, "flat": chunk-per-wave kernel always
         c->pipeline_forced = strcmp(pl, "doc") == 0 ? 2 : strcmp(pl, "flat") == 0 ? 1 : 0;
     *out_ctx = c;
@@ -310,6 +321,8 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     c->scratch_rec.release();
     c->f_late.release();
+    c->t_memo.release();
+    c->t_memo_log.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     DevBuf* pbufs[] = {&c->in_bytes2, &c->in_offs2, &c->out_ids2, &c->out_offs2};
@@ -547,6 +560,77 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
     return TK_OK;
 }
 
+// MEMO (tk_hash.h): the table is allocated at the first flat-pipeline call that wants it.  Adaptive policy (memo_account): a call's
+// hit rate = hits / (hits + pieces of 2..16 bytes the narrow merge kernel still had to merge); on text whose unknown pieces do not
+// come back (random code points: BASELINE configs[2]) or that has few of them (a vocabulary fitted to the text), the look-ups cost
+// more than the hits return, so after two such calls in a row the table is left alone for 30 calls, then tried again.
+// Whatever the policy does, ids never depend on it: an entry is the exact key and the pure merge of its bytes.
+static int memo_prepare(tk_ctx* c, TkFlatArgs& fa, hipStream_t s) {
+    fa.memo_tab = nullptr; fa.memo_mask = 0; fa.memo_epoch = 0; fa.memo_hits = nullptr;
+    fa.memo_log = nullptr; fa.memo_log_counts = nullptr; fa.memo_log_per_wave = 0; fa.memo_log_waves = 0;
+    c->memo_active_last = false;
+    if (c->memo_log2 == 0) return TK_OK;
+    if (c->memo_policy == 0 && c->memo_pause) { --c->memo_pause; return TK_OK; }
+    const size_t bytes = ((size_t)1 << c->memo_log2) * sizeof(tk_memo_entry);
+    if (c->memo_have_log2 != c->memo_log2) {
+        c->t_memo.release();
+        if (c->t_memo.reserve(bytes) != hipSuccess) {      // no room: the memo is an optimisation, the call goes on without it
+            (void)hipGetLastError();
+            c->memo_log2 = 0; c->memo_have_log2 = 0;
+            return TK_OK;
+        }
+        TK_HIP(c, hipMemsetAsync(c->t_memo.p, 0, bytes, s));
+        c->memo_have_log2 = c->memo_log2;
+        c->memo_epoch = 0;
+    }
+    if (c->memo_epoch >= 0xFFFFFFF0u) {                     // the claim word would wrap: start over
+        TK_HIP(c, hipMemsetAsync(c->t_memo.p, 0, bytes, s));
+        c->memo_epoch = 0;
+    }
+    // the log of a call's new entries: one stretch per wave of the narrow merge kernel's grid (at most 16 waves on each CU), a
+    // quarter of the table in all, at most 2^21 records (what does not fit is dropped and comes again)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const uint32_t log_waves = (uint32_t)cus * 16u;
+    const uint32_t log_cap = 1u << (c->memo_log2 > 23 ? 21 : c->memo_log2 - 2);
+    const uint32_t per_wave = log_cap / log_waves > 0 ? log_cap / log_waves : 1u;
+    if (c->t_memo_log.reserve((size_t)per_wave * log_waves * sizeof(tk_memo_entry) + (size_t)log_waves * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        c->t_memo.release();
+        c->memo_log2 = 0; c->memo_have_log2 = 0;
+        return TK_OK;
+    }
+    fa.memo_tab = (tk_memo_entry*)c->t_memo.p;
+    fa.memo_mask = (1u << c->memo_log2) - 1u;
+    fa.memo_log = (tk_memo_entry*)c->t_memo_log.p;
+    fa.memo_log_counts = (uint32_t*)(fa.memo_log + (size_t)per_wave * log_waves);
+    fa.memo_log_per_wave = per_wave;
+    fa.memo_log_waves = log_waves;
+    TK_HIP(c, hipMemsetAsync(fa.memo_log_counts, 0, (size_t)log_waves * 4, s));   // (waves the grid does not launch log nothing)
+    fa.memo_epoch = ++c->memo_epoch;
+    fa.memo_hits = (uint32_t*)c->counters.p + 24;
+    c->memo_active_last = true;
+    return TK_OK;
+}
+static void memo_account(tk_ctx* c, const uint32_t* ctr28, uint64_t n_bytes) {
+    c->memo_hits_last = c->memo_lookups_last = 0;
+    if (!c->memo_active_last) return;
+    c->memo_hits_last = ctr28[24];
+    c->memo_lookups_last = (uint64_t)ctr28[24] + ctr28[25];
+    c->memo_hits_total += c->memo_hits_last;
+    c->memo_lookups_total += c->memo_lookups_last;
+    if (c->memo_policy != 0 || c->memo_epoch < 2 || n_bytes < (1u << 20)) return;   // (the first call fills an empty table)
+    // does it pay?  A look-up is one more dependent load in the flat kernel's miss path (measured on the 1 M x 512-byte shapes:
+    // +0.15 .. 0.18 ms whatever the number of look-ups), a hit saves a merge (~0.075 ms per million): under one hit per 160 bytes of
+    // text, or under three hits in ten look-ups (the mixed UTF-8 shape at 28 %: no gain, no loss), the table is left alone for 30 calls.
+    const bool pays = c->memo_hits_last * 10 >= c->memo_lookups_last * 3 && c->memo_hits_last * 160 >= n_bytes;
+    if (!pays) {
+        if (++c->memo_low_streak >= 2) { c->memo_pause = 30; c->memo_low_streak = 0; }
+    } else {
+        c->memo_low_streak = 0;
+    }
+}
+
 // The flat pipeline (tk_flat.hip): one wave per 2048-byte region of the packed stream, documents the
 // fast path cannot take (non-ASCII, very long runs / pieces) redone by the per-document kernels.
 static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs, uint64_t n_docs, uint64_t n_bytes,
@@ -637,6 +721,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     uint64_t* d_pfx = (uint64_t*)c->f_mpfx.p;                  // prefix sums over [4 C miss counts | C slot counts]
     const uint64_t* d_P = d_pfx + 4 * n_chunks;                // chunk slot prefix sums (offset by the miss total: only differences are used)
     TK_HIP(c, c->out_ids.reserve((n_bytes + 2 * n_docs + 64) * 4));
+    { int rcm = memo_prepare(c, fa, s); if (rcm != TK_OK) return rcm; }
     TK_HIP(c, hipEventRecord(c->ev[3], s));
     // (the pre-pass also clears the per-document flags / holes and the 16 counter words: no memset launches)
     TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, fa.flags, fa.holes, (uint32_t*)c->counters.p, s));
@@ -670,7 +755,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
         TK_HIP(c, hipEventRecord(c->ev_b[1], sb));
     }
     TK_HIP(c, tk_launch_scan(fa.miss_count, 5 * n_chunks, d_pfx, (uint64_t*)c->block_sums.p, s));
-    TK_HIP(c, tk_launch_merge(fa, s));
+    TK_HIP(c, tk_launch_merge(fa, (uint32_t*)c->counters.p + 25, s));
     TK_HIP(c, hipEventRecord(c->ev[4], s));
     uint64_t total = 0;
     auto finish = [&](int final_pass, bool wait) -> int {
@@ -683,7 +768,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
                                           final_pass ? nullptr : (const uint32_t*)ctr + 4, s));
         TK_HIP(c, hipEventRecord(c->ev[2], s));
         // every counter of the batch with one copy into pinned memory (6..7: the total, left there by the assembly)
-        TK_HIP(c, hipMemcpyAsync(c->h_pin, ctr, 64, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipMemcpyAsync(c->h_pin, ctr, 112, hipMemcpyDeviceToHost, s));   // (24, 25: memo hits, narrow pieces left to merge)
         if (wait) {
             TK_HIP(c, hipStreamSynchronize(s));
             ++c->host_syncs;
@@ -805,6 +890,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     (void)hipEventElapsedTime(&c->encode_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->pipeline_ms, c->ev[3], c->ev[2]);
     (void)hipEventElapsedTime(&c->merge_ms, c->ev[1], c->ev[4]);
+    memo_account(c, c->h_pin, n_bytes);
     *n_ids = total;
     return TK_OK;
 }
@@ -887,6 +973,40 @@ extern "C" int tk_encode_batch_device(tk_ctx* c, const void* d_bytes, const void
     *d_ids = c->out_ids.p;
     *d_out_offsets = c->out_offs.p;
     return TK_OK;
+}
+
+// The same entry with the checks a host caller gets from tk_encode_batch ("C callers get a `validate` flag"):
+// TK_CHECK_OFFSETS -- d_doc_offsets[0] == 0, non-decreasing, [n_docs] == n_bytes, or TK_ERR_INVALID_ARG (without it a bad offset
+// array is out-of-bounds indexing on the device); TK_CHECK_UTF8 -- every document is well-formed UTF-8 on its own (which includes:
+// no document starts inside a code point), or TK_ERR_INVALID_UTF8; implies the offsets check.  One small kernel and one host wait
+// each, before anything else runs.
+extern "C" int tk_encode_batch_device_ex(tk_ctx* c, const void* d_bytes, const void* d_doc_offsets, uint64_t n_docs,
+                                         uint64_t n_bytes, int add_bos, int add_eos, int checks, void* hip_stream, void** d_ids,
+                                         void** d_out_offsets, uint64_t* n_ids) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    if (checks & ~(TK_CHECK_OFFSETS | TK_CHECK_UTF8)) { std::lock_guard<std::mutex> lock(c->mu); c->err = "unknown check flag"; return TK_ERR_INVALID_ARG; }
+    if (checks) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!d_doc_offsets || (!d_bytes && n_bytes)) { c->err = "null argument"; return TK_ERR_INVALID_ARG; }
+        if (n_docs >= 0xFFFFFFF0ull) { c->err = "too many documents in one batch"; return TK_ERR_INVALID_ARG; }
+        TK_HIP(c, hipSetDevice(c->device));
+        hipStream_t s = (hipStream_t)hip_stream;
+        uint32_t* d_bad = (uint32_t*)c->counters.p + 2;
+        uint32_t bad = 0;
+        TK_HIP(c, hipMemsetAsync(d_bad, 0, 4, s));
+        TK_HIP(c, tk_launch_check_offsets((const uint64_t*)d_doc_offsets, n_docs, n_bytes, d_bad, s));
+        TK_HIP(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        if (bad) { c->err = "doc_offsets must start at 0, be non-decreasing and end at n_bytes (" + std::to_string(bad) + " violation(s))"; return TK_ERR_INVALID_ARG; }
+        if (checks & TK_CHECK_UTF8) {
+            TK_HIP(c, hipMemsetAsync(d_bad, 0, 4, s));
+            TK_HIP(c, tk_launch_validate((const uint8_t*)d_bytes, (const uint64_t*)d_doc_offsets, n_docs, d_bad, s));
+            TK_HIP(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+            TK_HIP(c, hipStreamSynchronize(s));
+            if (bad) { c->err = std::to_string(bad) + " document(s) are not valid UTF-8"; return TK_ERR_INVALID_UTF8; }
+        }
+    }
+    return tk_encode_batch_device(c, d_bytes, d_doc_offsets, n_docs, n_bytes, add_bos, add_eos, hip_stream, d_ids, d_out_offsets, n_ids);
 }
 
 static int check_offsets(tk_ctx* c, const uint64_t* doc_offsets, uint64_t n_docs) {
@@ -1262,6 +1382,40 @@ extern "C" int tk_last_timing(const tk_ctx* c, float* pipeline_ms, float* encode
     if (!c) return TK_ERR_INVALID_ARG;
     if (pipeline_ms) *pipeline_ms = c->pipeline_ms;
     if (encode_kernel_ms) *encode_kernel_ms = c->encode_ms;
+    return TK_OK;
+}
+
+extern "C" int tk_ctx_set_memo(tk_ctx* c, int log2_entries, int policy) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (log2_entries != 0 && (log2_entries < 10 || log2_entries > 26)) { c->err = "memo size: log2_entries must be 0 (off) or 10..26"; return TK_ERR_INVALID_ARG; }
+    if (policy != 0 && policy != 1) { c->err = "memo policy must be 0 (adaptive) or 1 (always)"; return TK_ERR_INVALID_ARG; }
+    c->memo_log2 = (uint32_t)log2_entries;
+    c->memo_policy = policy;
+    c->memo_pause = 0; c->memo_low_streak = 0;
+    if (log2_entries == 0) {
+        TK_HIP(c, hipSetDevice(c->device));
+        TK_HIP(c, hipDeviceSynchronize());
+        c->t_memo.release();
+        c->t_memo_log.release();
+        c->memo_have_log2 = 0;
+    }
+    return TK_OK;
+}
+extern "C" int tk_ctx_memo_clear(tk_ctx* c) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->memo_have_log2 = 0;         // (the next call that wants the table clears it on its own stream)
+    c->memo_pause = 0; c->memo_low_streak = 0;
+    return TK_OK;
+}
+extern "C" int tk_memo_stats(const tk_ctx* c, uint64_t* lookups_last, uint64_t* hits_last, uint64_t* lookups_total, uint64_t* hits_total, int* active_last) {
+    if (!c) return TK_ERR_INVALID_ARG;
+    if (lookups_last) *lookups_last = c->memo_lookups_last;
+    if (hits_last) *hits_last = c->memo_hits_last;
+    if (lookups_total) *lookups_total = c->memo_lookups_total;
+    if (hits_total) *hits_total = c->memo_hits_total;
+    if (active_last) *active_last = c->memo_active_last ? 1 : 0;
     return TK_OK;
 }
 

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     // document d owns the chunks whose lo lies in (doc_offs[d], doc_offs[d + 1]]  (the last document: everything above)
     const uint64_t d = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
     if (d == 0 && n_chunks) first_doc[0] = 0u;
-    if (d < 16) counters16[d] = 0u;                 // the batch's device counters
+    if (d < 16 || d == 24) counters16[d] = 0u;      // the batch's device counters (24: memo hits)
     if (d <= n_docs) { flags[d] = 0u; holes[d] = 0u; }
     if (d >= n_docs) return;
     const uint64_t s = doc_offs[d], e = doc_offs[d + 1];
@@ -66,6 +66,7 @@ __device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_
         c_step = nb * (TKF_BLOCK / 64);
     }
     for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE, PAT>(a, c, lane, lds);
+    tk_flat_flush_memo_hits(a, lds, lane);
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
@@ -111,6 +112,7 @@ __device__ __forceinline__ void tk_flat_cut_body(const TkFlatArgs& a, uint32_t* 
         if (a.t.key_hash_mode == 0u) tk_flat_chunk<DBG, 0, 0, 1>(a, c, lane, lds);
         else tk_flat_chunk<DBG, 1, 0, 1>(a, c, lane, lds);
     }
+    tk_flat_flush_memo_hits(a, lds, lane);
 }
 __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS_CUT];
@@ -126,9 +128,14 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_cut_split_kernel(TkFlatArgs
 // that the merge waves do not have to search the prefix sums
 __global__ __launch_bounds__(TKF_BLOCK) void tk_merge_wavefirst_kernel(const uint64_t* __restrict__ prefix, uint64_t n_chunks,
                                                                         uint32_t* __restrict__ wave_first,
-                                                                        uint32_t* __restrict__ wave_first_wide) {
+                                                                        uint32_t* __restrict__ wave_first_wide,
+                                                                        uint32_t* __restrict__ narrow_left_out) {
     const uint64_t e = (uint64_t)blockIdx.x * TKF_BLOCK + threadIdx.x;
     if (e >= 4 * n_chunks) return;
+    if (e == 0 && narrow_left_out) {   // pieces of 2..16 bytes left to the merge kernel: the memo's misses of this call (the host's hit-rate policy)
+        const uint64_t nl = prefix[2 * n_chunks];
+        *narrow_left_out = nl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nl;
+    }
     const bool wide = e >= 2 * n_chunks;
     const uint64_t first = wide ? prefix[2 * n_chunks] : 0;
     const uint64_t lo = prefix[e] - first, hi = prefix[e + 1] - first;
@@ -171,7 +178,26 @@ __global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   /
     const uint64_t n_waves = (uint64_t)gridDim.x * (TKM_BLOCK / 64);
     const uint64_t total = a.miss_prefix[2 * a.n_chunks];
     uint32_t* mlds = wlds + TKM_FWORDS + (threadIdx.x >> 6) * TKM_LDS_WORDS(16);
-    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane(), mlds, TKM_FILTER ? wlds : nullptr);
+    TkMemoLog ml;
+    ml.base = a.memo_log ? a.memo_log + wave * a.memo_log_per_wave : nullptr;
+    ml.n = 0u;
+    ml.cap = a.memo_log && wave < a.memo_log_waves ? a.memo_log_per_wave : 0u;
+    for (uint64_t w = wave; w * 64 < total; w += n_waves) tk_merge_wave<false>(a, w, wv_lane(), mlds, TKM_FILTER ? wlds : nullptr, a.memo_log ? &ml : nullptr);
+    if (a.memo_log && wave < a.memo_log_waves && wv_lane() == 0) a.memo_log_counts[wave] = ml.n;
+}
+
+// the log of the merge kernel's new memo entries into the table: claim, then commit (tk_memo_claim_one / tk_memo_commit_one)
+__global__ __launch_bounds__(TKF_BLOCK) void tk_memo_claim_kernel(tk_memo_entry* __restrict__ tab, const tk_memo_entry* __restrict__ log,
+                                                                   const uint32_t* __restrict__ counts, uint32_t per_wave, uint32_t n_waves) {
+    const uint32_t n = per_wave * n_waves;
+    for (uint32_t i = blockIdx.x * TKF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TKF_BLOCK)
+        if (tk_memo_log_live(counts, per_wave, i)) tk_memo_claim_one(tab, log, i);
+}
+__global__ __launch_bounds__(TKF_BLOCK) void tk_memo_commit_kernel(tk_memo_entry* __restrict__ tab, const tk_memo_entry* __restrict__ log,
+                                                                    const uint32_t* __restrict__ counts, uint32_t per_wave, uint32_t n_waves) {
+    const uint32_t n = per_wave * n_waves;
+    for (uint32_t i = blockIdx.x * TKF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TKF_BLOCK)
+        if (tk_memo_log_live(counts, per_wave, i)) tk_memo_commit_one(tab, log, i);
 }
 
 __global__ __launch_bounds__(TKM_WIDE_BLOCK) void tk_merge_wide_kernel(TkFlatArgs a) {   // pieces of 17..64 bytes
@@ -434,7 +460,7 @@ static uint32_t tkf_blocks(uint64_t n_threads) { return (uint32_t)((n_threads + 
 hipError_t tk_launch_flat_firstdoc(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_chunks, uint32_t* first_doc,
                                    uint32_t* flags, uint32_t* holes, uint32_t* counters16, hipStream_t s) {
     // (always launched: it also clears flags / holes [n_docs + 1] and the counters)
-    hipLaunchKernelGGL(tk_flat_firstdoc_kernel, dim3(tkf_blocks(n_docs + 16)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs,
+    hipLaunchKernelGGL(tk_flat_firstdoc_kernel, dim3(tkf_blocks(n_docs + 32)), dim3(TKF_BLOCK), 0, s, doc_offs, n_docs,
                        n_chunks, first_doc, flags, holes, counters16);
     return hipGetLastError();
 }
@@ -474,7 +500,7 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint32_t* narrow_left_out, hipStream_t s) {
     if (a.n_chunks == 0) return hipSuccess;
     // persistent grids (the number of queued pieces stays on the device): the blocks that are resident at once -- each
     // one copies the PAIR filter into its LDS first -- and never more than the sub-queues could fill
@@ -502,9 +528,15 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s) {
     if (b1 > res1) b1 = res1;
     if (b2 > res2) b2 = res2;
     hipLaunchKernelGGL(tk_merge_wavefirst_kernel, dim3(tkf_blocks(4 * a.n_chunks)), dim3(TKF_BLOCK), 0, s, a.miss_prefix,
-                       a.n_chunks, a.wave_first, a.wave_first_wide);
+                       a.n_chunks, a.wave_first, a.wave_first_wide, narrow_left_out);
+    // (the memo log is cut into one stretch per wave of THIS grid; a grid with more waves than the log was sized for logs nothing
+    // from the surplus waves)
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKM_BLOCK), TKM_LDS_BYTES, s, a);
     hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKM_WIDE_BLOCK), TKM_WIDE_LDS_BYTES, s, a);
+    if (a.memo_tab && a.memo_log) {
+        hipLaunchKernelGGL(tk_memo_claim_kernel, dim3(1024), dim3(TKF_BLOCK), 0, s, a.memo_tab, a.memo_log, a.memo_log_counts, a.memo_log_per_wave, a.memo_log_waves);
+        hipLaunchKernelGGL(tk_memo_commit_kernel, dim3(1024), dim3(TKF_BLOCK), 0, s, a.memo_tab, a.memo_log, a.memo_log_counts, a.memo_log_per_wave, a.memo_log_waves);
+    }
     return hipGetLastError();
 }
 

@@ -74,6 +74,17 @@ struct TkFlatArgs {
     uint32_t* late_list;         // [n_docs] documents that a long-piece record flags (an open piece beyond TKF_LONGCAP) after the list of
                                  // the handed-back documents was made; NULL: the flag alone (the list is made afterwards)
     uint32_t* late_count;
+    tk_memo_entry* memo_tab;     // memo of merged pieces (tk_hash.h MEMO; NULL: off), memo_mask + 1 entries: read by the flat kernel for a piece
+                                 // of 2..16 bytes that is no vocabulary key -- a hit reserves exactly its ids' slots and stores them: no queue
+                                 // entry, no holes
+    uint32_t memo_mask;          // entries - 1
+    uint32_t memo_epoch;         // number of this call (> 0, rising): the claim word of tk_memo_commit_one
+    uint32_t* memo_hits;         // device counter: memo hits of the call (the host's hit-rate policy); may be NULL
+    tk_memo_entry* memo_log;     // what the merge kernel merged into <= TK_MEMO_MAXIDS ids in this call (epoch word = table slot): merge wave w
+                                 // owns records [w * memo_log_per_wave, (w + 1) * memo_log_per_wave) and leaves their number in
+                                 // memo_log_counts[w]; tk_memo_claim_kernel / tk_memo_commit_kernel move them into the table
+    uint32_t* memo_log_counts;   // [memo_log_waves]
+    uint32_t memo_log_per_wave, memo_log_waves;
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags
     int pattern;                 // 0: the reference's hard-coded pattern; 1: the JSON pattern of tekken.json (row f-3, opt-in)
     int dbg_ablate;              // timing-only ablation bits (TK_DEBUG_ABLATE): 1 no probes, 2 no merges, 4 no id stores,

@@ -35,6 +35,7 @@ hipError_t tk_launch_compact(const uint32_t* staging, const uint64_t* doc_offs, 
                              const uint64_t* out_offs, uint64_t n_docs, uint32_t* out_ids, hipStream_t s);
 
 // UTF-8 validation of every document; *d_bad receives the number of invalid documents
+hipError_t tk_launch_check_offsets(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint32_t* d_bad, hipStream_t s);
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s);
 
@@ -56,7 +57,7 @@ hipError_t tk_launch_flat_counts(const uint64_t* doc_offs, uint64_t n_docs, uint
 hipError_t tk_launch_flat_assemble(uint64_t n_docs, const void* doc_info, const uint32_t* kcount, const uint64_t* out_offs,
                                    const uint32_t* tmp, const uint32_t* staging, uint32_t* out_ids, uint32_t bos_id,
                                    uint32_t eos_id, int add_bos, int add_eos, uint64_t* total_out, const uint32_t* skip_if, hipStream_t s);
-hipError_t tk_launch_merge(const TkFlatArgs& a, hipStream_t s);  // both merge kernels, persistent grids
+hipError_t tk_launch_merge(const TkFlatArgs& a, uint32_t* narrow_left_out, hipStream_t s);  // both merge kernels, persistent grids
 
 hipError_t tk_launch_iota(uint32_t* out, uint64_t n, hipStream_t s);   // out[i] = i
 hipError_t tk_launch_add_u64(uint64_t* p, uint64_t n, uint64_t add, hipStream_t s);   // p[i] += add

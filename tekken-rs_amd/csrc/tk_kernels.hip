@@ -257,6 +257,23 @@ __global__ __launch_bounds__(TK_BLOCK) void tk_validate_kernel(const uint8_t* __
     }
 }
 
+// the document offsets of a device-resident batch (tk_encode_batch_device_ex): [0] == 0, non-decreasing, [n_docs] == n_bytes --
+// what every kernel of the pipeline indexes with.  *bad counts the violations.
+__global__ __launch_bounds__(TK_BLOCK) void tk_check_offsets_kernel(const uint64_t* __restrict__ doc_offs, uint64_t n_docs, uint64_t n_bytes,
+                                                                     uint32_t* bad) {
+    const uint64_t d = (uint64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    bool err = false;
+    if (d == 0) err = doc_offs[0] != 0ull || doc_offs[n_docs] != n_bytes;
+    if (d < n_docs) err = err || doc_offs[d + 1] < doc_offs[d] || doc_offs[d + 1] > n_bytes;
+    const uint64_t m = __ballot(err);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(bad, (uint32_t)__builtin_popcountll(m));
+}
+hipError_t tk_launch_check_offsets(const uint64_t* doc_offs, uint64_t n_docs, uint64_t n_bytes, uint32_t* d_bad, hipStream_t s) {
+    const uint64_t blocks = (n_docs + 1 + TK_BLOCK - 1) / TK_BLOCK;
+    hipLaunchKernelGGL(tk_check_offsets_kernel, dim3((uint32_t)blocks), dim3(TK_BLOCK), 0, s, doc_offs, n_docs, n_bytes, d_bad);
+    return hipGetLastError();
+}
+
 hipError_t tk_launch_validate(const uint8_t* bytes, const uint64_t* doc_offs, uint64_t n_docs, uint32_t* d_bad,
                               hipStream_t s) {
     if (n_docs == 0) return hipSuccess;

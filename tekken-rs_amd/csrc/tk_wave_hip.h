@@ -59,6 +59,9 @@ TK_DEV uint64_t wv_brev64(uint64_t x) { return __builtin_bitreverse64(x); }  // 
 
 TK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 TK_DEV uint32_t wv_atomic_exch(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
+TK_DEV uint32_t wv_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+// a word other CUs (other XCDs: other L2s) update with device-scope atomics during this kernel: read it where they land
+TK_DEV uint32_t wv_load_coherent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // executed by ALL 64 lanes in uniform control flow: *p += 64*v, lane i receives old + i*v
 TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -31,6 +31,10 @@ def lib():
         L.emu_flat_encode_batch.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                             u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, u64p, u8p, u8p,
                                             u64p, u64p, ctypes.c_int]
+        L.emu_memo_set.restype = None
+        L.emu_memo_set.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.emu_memo_info.restype = None
+        L.emu_memo_info.argtypes = [u64p]
         L.emu_long_merge.restype = ctypes.c_int64
         L.emu_long_merge.argtypes = [u8p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, u8p, ctypes.c_uint32, u32p, u64p]
         _LIB = L
@@ -101,6 +105,29 @@ def flat_encode_batch(token_bytes, num_special, bos, eos, docs, add_bos=True, ad
         a, b = int(offs[d]), int(offs[d + 1])
         starts.append([i for i in range(b - a) if dbg[a + i]])
     return ids, starts, [d for d in range(D) if fl[d]]
+
+
+_MEMO_BUF = None
+
+
+def memo_set(log2):
+    """A memo table (csrc/tk_hash.h MEMO) for the following flat_encode_batch calls, kept across them like a context keeps its
+    own across tk_encode_batch calls; log2 = 0 switches it off.  The table is empty afterwards."""
+    global _MEMO_BUF
+    if not log2:
+        lib().emu_memo_set(None, 0)
+        _MEMO_BUF = None
+        return
+    raw = np.zeros((8 << log2) + 8, np.uint32)
+    skip = (-raw.ctypes.data % 32) // 4
+    _MEMO_BUF = raw                              # (kept alive: the emulator holds a pointer into it)
+    lib().emu_memo_set(raw.ctypes.data + 4 * skip, log2)
+
+
+def memo_info():
+    out = np.zeros(3, np.uint64)
+    lib().emu_memo_info(_p(out, ctypes.c_uint64))
+    return dict(calls=int(out[0]), hits_last=int(out[1]), entries=int(out[2]))
 
 
 def table_info(token_bytes, num_special):

@@ -96,6 +96,21 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
     return TK_OK;
 }
 
+// MEMO (tk_hash.h) on the emulator: a table the test owns, kept across emu_flat_encode_batch calls like the context's across
+// tk_encode_batch calls (log2 = 0: off).  emu_memo_info: {calls that used it, hits of the last call, valid entries}.
+static tk_memo_entry* g_memo = nullptr;
+static uint32_t g_memo_mask = 0, g_memo_epoch = 0, g_memo_hits = 0, g_memo_log_cap = 0;
+extern "C" void emu_memo_set(uint32_t* table_words, uint32_t log2) {
+    g_memo = log2 ? reinterpret_cast<tk_memo_entry*>(table_words) : nullptr;
+    g_memo_mask = log2 ? (1u << log2) - 1u : 0u;
+    g_memo_log_cap = log2 ? (log2 > 4 ? 1u << (log2 - 2) : 3u) : 0u;   // (a tiny log as well: dropped entries are part of the design)
+    g_memo_epoch = 0; g_memo_hits = 0;
+}
+extern "C" void emu_memo_info(uint64_t* out) {
+    out[0] = g_memo_epoch; out[1] = g_memo_hits; out[2] = 0;
+    if (g_memo) for (uint32_t i = 0; i <= g_memo_mask; ++i) out[2] += tk_memo_len(g_memo[i].v[2]) != 0u;
+}
+
 // Flat path on the emulator: tk_flat_chunk for every chunk (one emulated wave), the flagged documents through
 // the per-document algorithm (mode 3, then pass 2), and host restatements of the small bookkeeping kernels of
 // tk_flat.hip (first_doc, todo list, chunk prefix sums, counts, assemble).
@@ -138,6 +153,16 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     fa.dbg_starts = dbg_starts;
     fa.pattern = pattern;
     fa.t = T.host_view();
+    if (g_memo) {
+        if (reinterpret_cast<uintptr_t>(g_memo) % 32) { g_err = "memo table must be 32-byte aligned"; return TK_ERR_INVALID_ARG; }
+        g_memo_hits = 0;
+        fa.memo_tab = g_memo; fa.memo_mask = g_memo_mask; fa.memo_epoch = ++g_memo_epoch; fa.memo_hits = &g_memo_hits;
+    }
+    // the log: three "waves" (the narrow groups are dealt out over them), each with its own stretch
+    const uint32_t memo_waves = 3;
+    std::vector<tk_memo_entry> memo_log((size_t)g_memo_log_cap * memo_waves + 1);
+    std::vector<uint32_t> memo_log_counts(memo_waves, 0);
+    if (g_memo) { fa.memo_log = memo_log.data(); fa.memo_log_counts = memo_log_counts.data(); fa.memo_log_per_wave = g_memo_log_cap; fa.memo_log_waves = memo_waves; }
     // pieces of 65..TKF_LONGCAP bytes stay on the flat path as records (TK_FLAT_LONG=0: they hand their documents back)
     std::vector<TkFlatLongRec> long_recs(n_bytes / 65 + 16);
     std::vector<uint32_t> ctlblk(24, 0);                    // the context's counter block: counter 11, control words 16..18
@@ -170,6 +195,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
                 } else if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0>(fa, c, lane, lds.data()); }
                 else { if (m1) tk_flat_chunk<0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<0, 0>(fa, c, lane, lds.data()); }   // production
             }
+            tk_flat_flush_memo_hits(fa, lds.data(), lane);
         });
         ops += tkemu::g_wave->n_ops;
         if (fa.cut_list && ctlblk[12]) {                    // tk_flat_cut_kernel
@@ -182,7 +208,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
                     if (fa.dbg_starts) { if (m1) tk_flat_chunk<1, 1, 0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<1, 0, 0, 1>(fa, c, lane, lds.data()); }
                     else { if (m1) tk_flat_chunk<0, 1, 0, 1>(fa, c, lane, lds.data()); else tk_flat_chunk<0, 0, 0, 1>(fa, c, lane, lds.data()); }
                 }
-            });
+                });
             ops += tkemu::g_wave->n_ops;
         }
         if (getenv("TK_EMU_LOG")) fprintf(stderr, "[emu] chunks %llu, cut chunks %u, long records %u\n", (unsigned long long)n_chunks, ctlblk[12], ctlblk[11]);
@@ -208,7 +234,13 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             return true;
         };
         for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
-            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data() + G, fa.t.pair_filter); });
+            TkMemoLog ml;
+            const uint32_t mw = (uint32_t)(w % memo_waves);
+            ml.base = fa.memo_log ? fa.memo_log + (size_t)mw * fa.memo_log_per_wave : nullptr;
+            ml.n = fa.memo_log ? memo_log_counts[mw] : 0u;
+            ml.cap = fa.memo_log ? fa.memo_log_per_wave : 0u;
+            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data() + G, fa.t.pair_filter, fa.memo_log ? &ml : nullptr); });
+            if (fa.memo_log) memo_log_counts[mw] = ml.n;
             if (!guards_ok(TKM_LDS_WORDS(16))) { g_err = "tk_merge_wave<false> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
@@ -227,6 +259,16 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
                 if (mlds64[i] != 0xDEADBEEFu || mlds64[G + TKM_LDS_WORDS(64) + i] != 0xDEADBEEFu) { g_err = "tk_merge_wave_long3 wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
+    }
+    if (fa.memo_tab) {                                      // tk_memo_commit_kernel
+        const uint32_t nl = fa.memo_log_per_wave * fa.memo_log_waves;
+        for (uint32_t i = 0; i < nl; ++i) {
+            if (!tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) continue;
+            if (memo_log[i].epoch > fa.memo_mask) { g_err = "memo log: slot out of range"; return TK_ERR_RUNTIME; }
+            tk_memo_claim_one(fa.memo_tab, memo_log.data(), i);
+        }
+        for (uint32_t i = 0; i < nl; ++i)
+            if (tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) tk_memo_commit_one(fa.memo_tab, memo_log.data(), i);
     }
     // the long-piece records (tk_flat_long_kernel): one wave each; a piece beyond TKF_LONGCAP flags its document; those of up
     // to 128 bytes that are no vocabulary keys go on to the lane-per-piece merge (tk_flat_long128_kernel)

@@ -286,6 +286,13 @@ TK_DEV uint32_t wv_atomic_exch(uint32_t* p, uint32_t v) {
     return old;
 }
 
+TK_DEV uint32_t wv_load_coherent(const uint32_t* p) { return *p; }
+TK_DEV uint32_t wv_atomic_max(uint32_t* p, uint32_t v) {
+    uint32_t old = *p;
+    if (v > old) *p = v;
+    return old;
+}
+
 TK_DEV uint32_t wv_atomic_add_all(uint32_t* p, uint32_t v) {
     tkemu::Wave* w = tkemu::g_wave;
     int lane = w->cur;

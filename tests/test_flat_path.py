@@ -424,3 +424,42 @@ def test_pair_filter_has_no_false_negatives(test_vocab, small_vocab):
     assert emu.table_info(test_vocab["tokens"], test_vocab["num_special"])["pairs"] > 0
     with tempfile.TemporaryDirectory() as d:
         emu.table_cache_roundtrip(test_vocab["tokens"], test_vocab["num_special"], d + "/t.bin")
+
+
+def test_emu_memo_of_merged_pieces(test_vocab, small_vocab):
+    """The memo of merged pieces (csrc/tk_hash.h MEMO): pieces of 2..16 bytes that are no vocabulary key are looked up in a table
+    the narrow merge kernel fills, from the next call on.  Every call -- table empty, half filled, tiny and thrashing, hit by
+    fragments of cut pieces, under the other vocabulary's leftovers being impossible by construction (one table per vocabulary)
+    -- must give the oracle's ids; and the second pass over the same text must actually hit."""
+    rng = random.Random(11)
+    words = ["zyqx", "Qwrtzu", "blorft", "xx", "Zz", "quuxly", "vvvvvv", "aeiouaeiou", "snorkelwhack", "pneumonoultra", "ZYXWVUTSRQPONMLK"]
+    def text(n):
+        out = []
+        for _ in range(n):
+            w = rng.choice(words) if rng.random() < 0.5 else "".join(rng.choice("abcxyzQZ") for _ in range(rng.randint(2, 18)))
+            out.append(w)
+        return (" ".join(out)).encode()
+    docs_a = [text(rng.randint(0, 60)) for _ in range(30)] + list(helpers.EDGE_DOCS) + [b"x" * 300 + b" zyqx blorft", ("qz" * 80).encode()]
+    docs_b = [text(rng.randint(0, 60)) for _ in range(30)] + docs_a[:10]
+    d, o = corpus.generate("ascii", 30, 512, seed=corpus.BASE_SEED + 1)
+    docs_c = corpus.docs_of(d, o)
+    try:
+        for v in (test_vocab, small_vocab):
+            for log2 in (12, 4):                 # roomy, and 16 entries (every insert evicts something)
+                emu.memo_set(log2)
+                seen_hits = 0
+                for docs in (docs_a, docs_a, docs_b, docs_c, docs_a, docs_c):
+                    _emu_check(v, docs, check_split=False)
+                    seen_hits += emu.memo_info()["hits_last"]
+                info = emu.memo_info()
+                assert info["calls"] == 6 and info["entries"] > 0
+                assert seen_hits > 0, "no call ever hit the memo"
+                _emu_check(v, docs_a, False, False, check_split=False)
+        # a hit is reported only for what the table holds: first call 0, an identical second call > 0
+        emu.memo_set(14)
+        _emu_check(test_vocab, docs_a, check_split=False)
+        assert emu.memo_info()["hits_last"] == 0
+        _emu_check(test_vocab, docs_a, check_split=False)
+        assert emu.memo_info()["hits_last"] > 0
+    finally:
+        emu.memo_set(0)

@@ -863,3 +863,97 @@ def test_long_pieces_merged_in_rounds(tk, test_vocab, bench_vocab, monkeypatch):
         took += e.round_path_docs()
         e.close()
     assert took > 100
+
+
+def test_device_entry_checks_offsets_and_utf8(tk, eng_small, test_vocab):
+    """tk_encode_batch_device_ex ("C callers get a validate flag"): corrupted offsets are TK_ERR_INVALID_ARG, a document that
+    is not UTF-8 on its own -- one that starts inside a code point included -- is TK_ERR_INVALID_UTF8, a good batch gives the ids
+    of the unchecked entry."""
+    import torch
+    docs = [b"hello world", "café 中文".encode(), b"", b"tail"]
+    data, offs = helpers_pack(docs)
+    d_b = torch.from_numpy(data).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    orc = helpers.oracle_for(test_vocab)
+    eids, eoo = orc.encode_batch(data, offs, True, True)
+
+    def run(o, checks, n_bytes=None):
+        d_o = torch.from_numpy(np.asarray(o, dtype=np.uint64).astype(np.int64)).cuda()
+        v_ids, v_oo = None, None
+        p_ids, p_oo, n = eng_small.encode_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(o) - 1, len(data) if n_bytes is None else n_bytes,
+                                                       True, True, stream, checks=checks)
+        ids = torch.as_tensor(tk.DeviceView(p_ids, n, "<i4"), device="cuda").cpu().numpy().view(np.uint32)
+        return ids
+
+    for checks in (tk.CHECK_OFFSETS, tk.CHECK_OFFSETS | tk.CHECK_UTF8, tk.CHECK_UTF8):
+        assert np.array_equal(run(offs, checks), eids)
+    good = [int(x) for x in offs]
+    bad_sets = [[1] + good[1:], good[:2] + [good[1] - 1] + good[3:], good[:-1] + [good[-1] + 5], good[:-1] + [good[-1] - 1],
+                [good[0], good[3], good[3] - 1, good[3], good[4]]]
+    for o in bad_sets:
+        with pytest.raises(tk.TokenizerError) as e:
+            run(o, tk.CHECK_OFFSETS)
+        assert e.value.code == tk.TK_ERR_INVALID_ARG, o
+    # a boundary inside the two-byte char of document 1: offsets are fine, the documents are not UTF-8 on their own
+    cut = good[1] + 4
+    assert data[cut] & 0xC0 == 0x80
+    split = [good[0], good[1], cut, good[3], good[4]]
+    assert len(run(split, tk.CHECK_OFFSETS)) > 0             # (only the offsets are checked: accepted)
+    with pytest.raises(tk.TokenizerError) as e:
+        run(split, tk.CHECK_UTF8)
+    assert e.value.code == tk.TK_ERR_INVALID_UTF8
+    with pytest.raises(tk.TokenizerError) as e:
+        run(offs, 64)
+    assert e.value.code == tk.TK_ERR_INVALID_ARG
+
+
+def helpers_pack(docs):
+    offs = np.zeros(len(docs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(d) for d in docs], dtype=np.uint64)
+    return np.frombuffer(b"".join(docs) or b"\0", dtype=np.uint8).copy(), offs
+
+
+def test_memo_never_changes_an_id(tk, test_vocab, bench_vocab):
+    """The memo of merged pieces (tk_ctx_set_memo; csrc/tk_hash.h MEMO): call after call on one context -- table empty, filling, full
+    of another text's words, tiny and thrashing, cleared, switched off and on again, adaptive policy and always-on -- every call
+    gives the oracle's ids, and a repeated text actually hits the table."""
+    rng = np.random.default_rng(5)
+    for v in (test_vocab, bench_vocab):
+        orc = helpers.oracle_for(v)
+        eng = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
+        try:
+            batches = []
+            for sd, kind, n, dl in ((1, "ascii", 3000, 512), (2, "mixed", 400, 2048), (4, "zipf", 1500, 0), (7, "ascii", 3000, 512)):
+                data, offs = corpus.generate(kind, n, dl, seed=corpus.BASE_SEED + sd)
+                batches.append((data, offs))
+            # words no vocabulary has: every one of them goes through the merge, and comes back in the next batch
+            words = ["".join(rng.choice(list("qxzjkvwQXZ"), size=int(rng.integers(2, 8)))) for _ in range(400)]
+            junk = [(" ".join(rng.choice(words, size=int(rng.integers(1, 80))))).encode() for _ in range(600)]
+            batches.append(helpers_pack(junk))
+            batches.append(helpers_pack(list(helpers.EDGE_DOCS)))
+            for log2, policy in ((18, 1), (10, 1), (16, 0)):
+                eng.set_memo(log2, policy)
+                hits = 0
+                for rnd in range(3):
+                    for data, offs in batches:
+                        check_batch(eng, orc, data, offs)
+                        st = eng.memo_stats()
+                        hits += st["hits_last"]
+                        assert st["hits_last"] <= st["lookups_last"]
+                    if rnd == 1:
+                        eng.memo_clear()
+                if policy == 1:
+                    assert hits > 0, "the memo was never hit (log2 %d)" % log2
+            eng.set_memo(0)
+            check_batch(eng, orc, *batches[0])
+            assert not eng.memo_stats()["active_last"]
+            eng.set_memo(20, 1)
+            check_batch(eng, orc, *batches[4])
+            check_batch(eng, orc, *batches[4])
+            st = eng.memo_stats()
+            assert st["active_last"] and st["hits_last"] > 0.3 * st["lookups_last"], st
+            for bad in (5, 27, -1):
+                with pytest.raises(tk.TokenizerError):
+                    eng.set_memo(bad)
+        finally:
+            eng.close()

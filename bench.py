@@ -131,6 +131,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = dry run of the N>1 code path with several ranks sharing one GPU (ids staged through host)")
     ap.add_argument("--single-docs", type=int, default=1000, help="single_doc leg: sequential one-document calls (C1 shape: 64-byte strings), 0 = skip")
+    ap.add_argument("--fresh-batches", type=int, default=0,
+                    help="B >= warmup + steps distinct seeded batches resident in HBM, step k runs on batch k, and the memo of merged pieces "
+                         "(tk_ctx_set_memo) is ON: the only protocol under which a persistent cache may be timed.  0 (default): one batch repeated, memo OFF")
+    ap.add_argument("--extra-legs", default="auto", help="auto: at N = 1 on the default shape also run compact legs for configs[2], one GPU's share of "
+                                                           "configs[4] and the held-out vocabulary (fresh batches, memo on and off); none: skip")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline_nt: oracle threads (0 = all host cores, capped at 256; 1 = skip)")
     args = ap.parse_args()
     if args.steps <= 0:
@@ -198,6 +203,24 @@ def main():
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
+    # The memo of merged pieces is a persistent cache: on ONE repeated batch it would answer every unknown piece from the second step
+    # on -- work skipped in the timed region.  So: repeated batch (the default) => memo OFF; --fresh-batches B => B distinct batches
+    # (seeds apart), step k on batch k, memo on with its adaptive policy, and the line says so.
+    fresh = []
+    if args.fresh_batches:
+        if args.fresh_batches < args.warmup + args.steps:
+            raise SystemExit("--fresh-batches %d < warmup + steps = %d: a batch would repeat" % (args.fresh_batches, args.warmup + args.steps))
+        if distributed and args.kind == "zipf":
+            raise SystemExit("--fresh-batches is not wired for the byte-sharded zipf shape")
+        for k in range(args.fresh_batches):
+            dk, ok = corpus.generate(args.kind, n_docs, args.doc_len, seed=seed + 1000 * (k + 1), first_doc=first_doc, threads=min(64, os.cpu_count() or 1))
+            fresh.append((torch.from_numpy(dk).cuda(), torch.from_numpy(ok.astype(np.int64)).cuda(), int(ok[-1])))
+        data, offs, n_bytes = dk, ok, int(ok[-1])           # (the last batch: what the CPU legs and the bit-exact check look at)
+        d_bytes, d_offs = fresh[-1][0], fresh[-1][1]
+        torch.cuda.synchronize()
+    eng.set_memo(22 if fresh else 0, 0)
+    step_no = [0]
+    bytes_seen = [0]
 
     enc_ms = []
     pipe_ms = []
@@ -241,7 +264,14 @@ def main():
 
     def step():
         nonlocal n_ids_local, gathered
-        v_ids, v_oo = eng.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, True, True, stream)
+        if fresh:
+            fb, fo, fn = fresh[step_no[0] % len(fresh)]
+            step_no[0] += 1
+            v_ids, v_oo = eng.encode_batch_device_views(fb.data_ptr(), fo.data_ptr(), n_docs, fn, True, True, stream)
+            bytes_seen[0] += fn
+        else:
+            v_ids, v_oo = eng.encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, True, True, stream)
+            bytes_seen[0] += n_bytes
         n_ids_local = v_ids.__cuda_array_interface__["shape"][0]
         t = eng.last_timing()
         enc_ms.append(t["encode_kernel_ms"])
@@ -268,6 +298,7 @@ def main():
     enc_ms.clear()
     pipe_ms.clear()
     merge_ms.clear()
+    bytes_seen[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         v_ids, v_oo = step()
@@ -281,7 +312,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([n_bytes, n_ids_local, n_docs], dtype=torch.int64, device=xdev)
+        tot = torch.tensor([bytes_seen[0] // args.steps, n_ids_local, n_docs], dtype=torch.int64, device=xdev)
         dist.all_reduce(tot)
         total_bytes, total_ids, total_docs = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
         # per-GPU device time of the tokenization kernels (HIP events around the pipeline): load balance, and the node
@@ -291,7 +322,7 @@ def main():
         dist.all_gather(per_rank, mine)
         per_rank = [p.tolist() for p in per_rank]
     else:
-        total_bytes, total_ids, total_docs = n_bytes, n_ids_local, n_docs
+        total_bytes, total_ids, total_docs = bytes_seen[0] // args.steps, n_ids_local, n_docs
         per_rank = [[float(np.mean(pipe_ms)), float(n_bytes)]]
 
     if rank == 0 and distributed:
@@ -336,11 +367,13 @@ def main():
         shape = {"ascii": "%d x %d-byte ASCII docs (G-ascii)" % (n_docs, args.doc_len),
                  "mixed": "%d x %d-byte mixed UTF-8 docs (G-mixed)" % (n_docs, args.doc_len),
                  "zipf": "%d Zipf-length docs, 16 B - 32 KiB (G-zipf)" % n_docs}[args.kind]
+        protocol = ("%d fresh seeded batches resident in HBM, step k on batch k, memo of merged pieces ON (adaptive)" % len(fresh)) if fresh else \
+            "one batch repeated, memo of merged pieces OFF"
         if not distributed:
-            workload = "%s, 1 x MI355X = BASELINE %s" % (shape, cfg1)
+            workload = "%s, 1 x MI355X = BASELINE %s; %s" % (shape, cfg1, protocol)
         else:
-            workload = "%s per GPU = BASELINE %s, gather of the id buffers to rank 0 in the step (%s backend, %s, %d-bit ids on the wire)" % (
-                shape, cfgN, "RCCL" if args.dist_backend == "nccl" else "gloo: ranks share a GPU", "overlap" if overlap else "sync", 18 if codec else 32)
+            workload = "%s per GPU = BASELINE %s, gather of the id buffers to rank 0 in the step (%s backend, %s, %d-bit ids on the wire); %s" % (
+                shape, cfgN, "RCCL" if args.dist_backend == "nccl" else "gloo: ranks share a GPU", "overlap" if overlap else "sync", 18 if codec else 32, protocol)
         k_times = [p[0] for p in per_rank]
         kernel_only = total_bytes / 1e6 / (max(k_times) * 1e-3) if max(k_times) > 0 else None
         out = {
@@ -350,14 +383,19 @@ def main():
             "config": {"workload": workload, "baseline_config": cfg1 if not distributed else cfgN,
                        "docs_total": total_docs, "input_bytes_total": total_bytes, "ids_total": total_ids,
                        "vocab": vocab_kind, "add_bos": True, "add_eos": True, "sharding": sharding},
-            "roofline": dict({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                              "kernel": "tk_flat_kernel", "kernel_ms": round(k_ms, 4), "bytes_alg_per_launch": bytes_alg,
+            # achieved = algorithmic bytes of the batch / the time of ALL its kernels, first to last (HIP events around the
+            # pipeline on its stream) -- `frac` is that; the dominant kernel alone (the same bytes over ITS duration: it neither writes the
+            # final ids nor the output offsets, so this flatters) is kept as kernel_frac
+            "roofline": dict({"bound": "hbm", "achieved": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_info.pop("traffic_pipeline", None),
+                              "span": "every kernel of a step, first to last (pipeline_ms)", "pipeline_ms": round(float(np.mean(pipe_ms)), 4),
+                              "bytes_alg_per_launch": bytes_alg,
+                              "kernel": "tk_flat_kernel", "kernel_ms": round(k_ms, 4), "kernel_achieved": round(achieved, 2),
+                              "kernel_frac": round(achieved / HBM_PEAK_GBS, 5), "kernel_traffic": traffic,
                               # (the span from the end of that kernel to the end of both merge kernels, scans included: on text with many pieces
                               # outside the vocabulary -- configs[2] -- the merge kernels are the longest part of a step)
                               "merge_kernels_ms": round(float(np.mean(merge_ms)), 4) if merge_ms else None,
                               "longest_part": "tk_flat_kernel" if not merge_ms or k_ms >= float(np.mean(merge_ms)) else "tk_merge_kernel + tk_merge_wide_kernel",
-                              "pipeline_ms": round(float(np.mean(pipe_ms)), 4),
                               "pipeline_frac": round(bytes_alg / (float(np.mean(pipe_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                               "bound_by": bound_by}, **traffic_info),
             "tokens_per_s": round(total_ids / (elapsed / args.steps), 1),
@@ -377,13 +415,122 @@ def main():
             out["host_to_host"] = host_leg(args, tk, eng, data, offs, h_ids, h_oo)
         if not distributed and args.single_docs > 0:
             out["single_doc"] = single_doc_leg(args, tk, eng, vocab_path)
+        out["memo"] = dict(eng.memo_stats(), protocol=protocol)
         if not distributed and args.cpu_passes > 0:
             out.update(cpu_baseline(args, data, offs, vocab_path, h_ids, h_oo, n_bytes))
+        if distributed and args.cpu_passes > 0:
+            # rank 0's shard on rank 0's host cores, bounded (the contract: N = 1 only needs it; the line keeps it for every N)
+            v_i = torch.as_tensor(v_ids, device="cuda").cpu().numpy().view(np.uint32)
+            v_o = torch.as_tensor(v_oo, device="cuda").cpu().numpy().astype(np.uint64)
+            a2 = argparse.Namespace(**vars(args))
+            a2.cpu_sample_docs, a2.cpu_passes, a2.cpu_threads = min(args.cpu_sample_docs, 200_000), 1, 1
+            out.update(cpu_baseline(a2, data, offs, vocab_path, v_i, v_o, n_bytes))
+        if distributed:
+            out["link_model"] = link_model(world, per_rank, total_ids, total_docs, 18 if codec else 32, ms_per_step)
+        if not distributed and args.extra_legs == "auto" and args.kind == "ascii" and not args.vocab and args.vocab_fit == "same" \
+                and n_docs == 1_000_000 and args.doc_len == 512 and not fresh:
+            tokz.close()
+            tokz = None
+            del d_bytes, d_offs
+            torch.cuda.empty_cache()
+            out.update(extra_legs(args, tk))
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if tokz is not None:
+        tokz.close()
+
+
+def link_model(world, per_rank, total_ids, total_docs, wire_bits, ms_per_step):
+    """What DESIGN.md section 5 predicts for this line, so that a measured N > 1 step can be read against it: every peer sends its ids
+    (wire_bits each) and per-document counts (u32) straight to rank 0 over its own xGMI link, all peers at once; rank 0's kernels run
+    beside the transfers (overlap) -- a step costs max(kernels, slowest link)."""
+    ids_per_peer = total_ids / max(1, world)
+    docs_per_peer = total_docs / max(1, world)
+    bytes_per_peer = ids_per_peer * wire_bits / 8 + docs_per_peer * 4
+    link_gbs = 64.0                       # one xGMI link, one direction (MI355X_MICROARCH.md: ~153 GB/s both ways, 60-75 one way)
+    link_ms = bytes_per_peer / (link_gbs * 1e9) * 1e3 if world > 1 else 0.0
+    k_ms = max(p[0] for p in per_rank)
+    return {"peers": world - 1, "bytes_per_peer": int(bytes_per_peer), "assumed_link_GBps_one_way": link_gbs, "expected_link_ms": round(link_ms, 3),
+            "kernels_ms_max": round(k_ms, 3), "expected_step_ms_overlap": round(max(k_ms, link_ms), 3),
+            "expected_step_ms_sync": round(k_ms + link_ms, 3), "measured_step_ms": round(ms_per_step, 3),
+            "note": "the gather the north star prescribes bounds N > 1, not the kernels (DESIGN.md section 5)"}
+
+
+def shape_leg(tk, vocab_path, kind, n_docs, doc_len, steps, warmup=1, fresh=0, memo_log2=0, memo_policy=0, sample_docs=2000, seed_off=1):
+    """One compact line for another single-GPU configuration: `steps` timed passes (HIP events around the pipeline) over a batch
+    resident in HBM -- or, with fresh > 0, over `fresh` distinct seeded batches, one per pass, with the memo of merged pieces on
+    (cold = the first pass, warm = the passes from the third on) --, a sample of documents id for id against the oracle."""
+    import torch
+    import corpus
+    import synth_vocab as sv
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tk_oracle
+    tokz = tk.Tekkenizer.from_file(vocab_path, device=0)
+    eng = tokz.engine()
+    eng.set_memo(memo_log2, memo_policy)
+    stream = torch.cuda.current_stream().cuda_stream
+    toks, ns, bos, eos = sv.load_tokens(vocab_path)
+    orc = tk_oracle.Oracle(toks, ns, bos, eos)
+    rows, exact, alg = [], True, 0
+    n_b = max(1, fresh)
+    for b in range(n_b):
+        data, offs = corpus.generate(kind, n_docs, doc_len, seed=corpus.BASE_SEED + seed_off + 1000 * b, threads=min(64, os.cpu_count() or 1))
+        n_bytes = int(offs[-1])
+        d_b = torch.from_numpy(data).cuda()
+        d_o = torch.from_numpy(offs.astype(np.int64)).cuda()
+        reps = 1 if fresh else warmup + steps
+        for r in range(reps):
+            v_ids, v_oo = eng.encode_batch_device_views(d_b.data_ptr(), d_o.data_ptr(), n_docs, n_bytes, True, True, stream)
+            t = eng.last_timing()
+            m = eng.memo_stats()
+            rows.append({"batch": b, "pipeline_ms": t["pipeline_ms"], "flat_ms": t["encode_kernel_ms"], "merge_ms": t["merge_ms"],
+                         "lookups": m["lookups_last"], "hits": m["hits_last"], "active": m["active_last"], "timed": bool(fresh) or r >= warmup,
+                         "n_bytes": n_bytes})
+        n_ids = v_ids.__cuda_array_interface__["shape"][0]
+        alg = n_bytes + 16 * (n_docs + 1) + 4 * n_ids
+        if b == n_b - 1 or b == 0:
+            k = min(sample_docs, n_docs)
+            h_oo = torch.as_tensor(v_oo, device="cuda")[:k + 1].cpu().numpy().astype(np.uint64)
+            h_ids = torch.as_tensor(v_ids, device="cuda")[:int(h_oo[k])].cpu().numpy().view(np.uint32)
+            eids, eoo = orc.encode_batch(data[:int(offs[k])], offs[:k + 1], True, True, threads=8)
+            exact = exact and bool(np.array_equal(h_oo, eoo) and np.array_equal(h_ids, eids))
+            st = orc.miss_stats(data[:int(offs[k])], offs[:k + 1])
+        del d_b, d_o
+    stats = eng.last_stats()
     tokz.close()
+    timed = [r for r in rows if r["timed"]]
+    warm = [r for r in timed if r["batch"] >= 2] if fresh else timed
+    ms = float(np.mean([r["pipeline_ms"] for r in warm]))
+    nb = float(np.mean([r["n_bytes"] for r in warm]))
+    out = {"docs": n_docs, "input_bytes": int(nb), "steps_timed": len(warm), "ms": round(ms, 4), "MBps": round(nb / 1e6 / (ms * 1e-3), 1),
+           "pipeline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "flat_kernel_ms": round(float(np.mean([r["flat_ms"] for r in warm])), 4),
+           "merge_kernels_ms": round(float(np.mean([r["merge_ms"] for r in warm])), 4), "handed_back_docs": stats["handed_back"],
+           "miss_rate": round(st["missed"] / max(1, st["pieces"]), 4), "bit_exact_vs_cpu_sample_docs": min(sample_docs, n_docs), "bit_exact_vs_cpu": exact}
+    if fresh:
+        lk, ht = sum(r["lookups"] for r in warm), sum(r["hits"] for r in warm)
+        out.update({"protocol": "%d fresh seeded batches, one pass each, memo ON (policy %s); warm = batches 2..%d" % (fresh, "always" if memo_policy else "adaptive", fresh - 1),
+                    "cold_first_batch_ms": round(rows[0]["pipeline_ms"], 4), "second_batch_ms": round(rows[1]["pipeline_ms"], 4) if len(rows) > 1 else None,
+                    "memo_hit_rate_warm": round(ht / max(1, lk), 4), "memo_active_warm": all(r["active"] for r in warm)})
+    else:
+        out["protocol"] = "one batch repeated, memo OFF"
+    return out
+
+
+def extra_legs(args, tk):
+    """The other single-GPU configurations in the driver-run line (compact: a few passes each): BASELINE configs[2], one GPU's share of
+    configs[4], and configs[1] with the held-out vocabulary -- memo off on a repeated batch, and memo on over fresh batches."""
+    import synth_vocab as sv
+    out = {}
+    dflt, held = sv.ensure_default(), sv.ensure_heldout()
+    out["configs[2]"] = dict(shape_leg(tk, dflt, "mixed", 1_000_000, 2048, steps=3, seed_off=1), workload="1 M x 2 KiB mixed UTF-8 docs (G-mixed), 1 x MI355X = BASELINE configs[2]")
+    out["configs[4]_share"] = dict(shape_leg(tk, dflt, "zipf", 500_000, 0, steps=5, seed_off=1), workload="500 k Zipf-length docs 16 B - 32 KiB = one GPU's share of BASELINE configs[4]")
+    out["heldout"] = dict(shape_leg(tk, held, "ascii", 1_000_000, 512, steps=10, seed_off=1),
+                          workload="configs[1] shape, vocabulary that never saw ~15 % of the word occurrences (--vocab-fit heldout)")
+    out["heldout_memo"] = dict(shape_leg(tk, held, "ascii", 1_000_000, 512, steps=0, fresh=8, memo_log2=22, seed_off=1),
+                               workload="the same shape and vocabulary, memo of merged pieces on, measured on FRESH batches only")
+    return out
 
 
 def node_entry(args):

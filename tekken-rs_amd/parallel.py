@@ -77,7 +77,8 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
     """Variable-length gather of token ids (+ per-document id counts) to rank `dst`.
 
     local_ids: 1-D int32 tensor (uint32 ids reinterpreted), on the device of the backend.
-    local_doc_counts: 1-D int64 tensor, ids per local document.
+    local_doc_counts: 1-D integer tensor, ids per local document (travels as int32: a document has fewer than 2^31 ids, and the
+    counts of a million documents are 4 MB a peer instead of 8).
     codec: None (ids travel as they are) or an object with packed_numel / pack / unpack (Ids18Codec).
     Returns on dst: (ids tensor, doc_offsets tensor int64[D_total+1]) in rank order = document
     order; on other ranks: (None, None).  wait=False: a PendingGather (call .result() later); on a CUDA device
@@ -89,6 +90,7 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
     world = dist.get_world_size(group)
     dev = local_ids.device
     on_gpu = dev.type == "cuda"
+    local_doc_counts = local_doc_counts.to(torch.int32)
     sizes = torch.tensor([local_ids.numel(), local_doc_counts.numel()], dtype=torch.int64, device=dev)
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
@@ -116,7 +118,7 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
         n_cnt = [s[1] for s in all_sizes]
         with on_side():
             ids = torch.empty(sum(n_ids), dtype=local_ids.dtype, device=dev)
-            counts = torch.empty(sum(n_cnt), dtype=torch.int64, device=dev)
+            counts = torch.empty(sum(n_cnt), dtype=torch.int32, device=dev)
             ops, wires = [], []
             i0 = c0 = 0
             for r in range(world):
@@ -146,7 +148,7 @@ def gather_ids(local_ids, local_doc_counts, dst=0, group=None, codec=None, wait=
                 for w, n, out in wires:
                     codec.unpack(w, n, out)
                 offs = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
-                torch.cumsum(counts, 0, out=offs[1:])
+                torch.cumsum(counts, 0, dtype=torch.int64, out=offs[1:])
             if side is not None:
                 side.synchronize()
                 # allocated under the side stream, used (and eventually freed) by the caller on the main stream

@@ -230,6 +230,10 @@ int tk_node_n_devices(const tk_node* node);
 /* Device timings of the last tk_node_encode_batch: the slowest device's tokenization pipeline, and the exchange on the root
  * (first receive posted .. offsets rebased), milliseconds. */
 int tk_node_last_timing(const tk_node* node, float* kernels_ms_max, float* gather_ms);
+/* How the last batch was cut: text bytes and ids of every device's run (up to `cap` entries each; either pointer may be NULL).
+ * Returns the number of devices.  Runs are contiguous whole documents with balanced BYTES: no run exceeds the mean by more than
+ * one document. */
+int tk_node_last_shards(const tk_node* node, uint64_t* shard_bytes, uint64_t* shard_ids, int cap);
 
 /* Device timings of the last tk_encode_batch* call, from HIP events on the stream the kernels
  * ran on: whole pipeline and the dominant encode kernel alone (milliseconds). */

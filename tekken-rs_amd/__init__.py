@@ -161,8 +161,9 @@ def lib():
     L.tk_tokenizer_decode_batch.restype = ctypes.c_int
     L.tk_tokenizer_decode_batch.argtypes = [vp, u32p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(_TextResult), u64p]
     L.tk_last_timing.restype = ctypes.c_int
-    L.tk_last_merge_ms.restype = ctypes.c_float
-    L.tk_last_merge_ms.argtypes = [vp]
+    if hasattr(L, "tk_last_merge_ms"):   # (like tk_cut_chunks: a diagnostic that older builds of the library lack)
+        L.tk_last_merge_ms.restype = ctypes.c_float
+        L.tk_last_merge_ms.argtypes = [vp]
     L.tk_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.tk_last_stats.restype = ctypes.c_int
     L.tk_last_stats.argtypes = [vp, u64p, u64p]
@@ -226,6 +227,8 @@ def lib():
     L.tk_node_encode_batch_pinned.argtypes = [vp, u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, u32p, ctypes.c_uint64, u64p, u64p]
     L.tk_node_n_devices.restype = ctypes.c_int
     L.tk_node_n_devices.argtypes = [vp]
+    L.tk_node_last_shards.restype = ctypes.c_int
+    L.tk_node_last_shards.argtypes = [vp, u64p, u64p, ctypes.c_int]
     L.tk_node_last_timing.restype = ctypes.c_int
     L.tk_node_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.tk_tokenizer_json_pattern.restype = ctypes.c_char_p
@@ -485,7 +488,7 @@ class Engine:
     def last_timing(self):
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().tk_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
-        return {"pipeline_ms": a.value, "encode_kernel_ms": b.value, "merge_ms": float(lib().tk_last_merge_ms(self._h))}
+        return {"pipeline_ms": a.value, "encode_kernel_ms": b.value, "merge_ms": float(lib().tk_last_merge_ms(self._h)) if hasattr(lib(), "tk_last_merge_ms") else 0.0}
 
     def last_stats(self):
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
@@ -555,6 +558,10 @@ class Node:
         """tk_node_encode_batch_pinned: caller-owned buffers (host_empty: pinned -- nothing allocated or pinned per call).  Returns the
         number of ids written into ids_out; offs_out[: n_docs + 1] holds the id offsets."""
         assert data.dtype == np.uint8 and offs.dtype == np.uint64 and ids_out.dtype == np.uint32 and offs_out.dtype == np.uint64
+        # (the C side writes n_docs + 1 offsets and takes no capacity for them; every buffer is handed over as one flat block)
+        assert len(offs_out) >= len(offs), "offs_out holds %d offsets, the call writes %d" % (len(offs_out), len(offs))
+        for a in (data, offs, ids_out, offs_out):
+            assert a.flags["C_CONTIGUOUS"], "tk_node_encode_batch_pinned wants contiguous buffers"
         n = ctypes.c_uint64(0)
         dbuf = data if len(data) else np.zeros(1, np.uint8)
         rc = lib().tk_node_encode_batch_pinned(self._h, _p(dbuf, ctypes.c_uint8), _p(offs, ctypes.c_uint64), len(offs) - 1, int(add_bos),
@@ -567,6 +574,13 @@ class Node:
         a, b = ctypes.c_float(0), ctypes.c_float(0)
         lib().tk_node_last_timing(self._h, ctypes.byref(a), ctypes.byref(b))
         return {"kernels_ms_max": a.value, "gather_ms": b.value}
+
+    def last_shards(self):
+        """(text bytes, ids) of every device's run in the last batch (tk_node_last_shards)."""
+        n = self.n_devices()
+        b, i = (ctypes.c_uint64 * n)(), (ctypes.c_uint64 * n)()
+        lib().tk_node_last_shards(self._h, b, i, n)
+        return list(b), list(i)
 
 
 class _Pinned:

@@ -449,8 +449,10 @@ static int enqueue_pass2(tk_ctx* c, TkEncodeArgs a, const uint32_t* list, const 
     uint64_t blocks = (uint64_t)cus;                                       // one 16-wave block per CU (158 KB of LDS)
     if (walk_waves > fit) walk_waves = fit / 4 * 4;
     if (blocks > fit) blocks = fit;
-    uint64_t slices = waves2;
-    if (c->long_min) slices = std::max(slices, std::max(walk_waves, blocks));
+    // (with the round-based merges on -- the default -- the mode-1 pass-2 kernel is never launched: only the walk's waves and the
+    // merging workgroups own a slice.  Sizing for waves2 as well allocated up to 5.4 GB on the JSON-pattern path, where max_waves
+    // is 8192, for a batch with many handed-back 32 KiB documents)
+    const uint64_t slices = c->long_min ? std::max(walk_waves, blocks) : waves2;
     TK_HIP(c, c->scratch.reserve(slices * words * 4));
     a.todo_list = list;
     a.n_todo = n_bound;
@@ -745,6 +747,18 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     const bool serial = c->serial_tail;
     hipStream_t sb = serial ? s : c->stream_b;
     c->host_syncs = 0;
+    // From here on work is queued on TWO streams.  Whatever way this function is left on an error -- a failed reserve, a failed
+    // launch --, both have drained before the caller sees it: the next call's pre-pass runs on `s` alone and would otherwise race
+    // the tail of this batch (pass 1, the walk, the merges) for counts, staging and the counters.
+    struct JoinStreams {
+        hipStream_t a, b;
+        bool armed = true;
+        ~JoinStreams() {
+            if (!armed) return;
+            (void)hipStreamSynchronize(b);
+            (void)hipStreamSynchronize(a);
+        }
+    } join_guard{s, sb};
     if (!serial) {
         TK_HIP(c, hipEventRecord(c->ev_b[0], s));
         TK_HIP(c, hipStreamWaitEvent(sb, c->ev_b[0], 0));
@@ -892,6 +906,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     (void)hipEventElapsedTime(&c->merge_ms, c->ev[1], c->ev[4]);
     memo_account(c, c->h_pin, n_bytes);
     *n_ids = total;
+    join_guard.armed = false;      // (every path to here has waited for both streams already)
     return TK_OK;
 }
 

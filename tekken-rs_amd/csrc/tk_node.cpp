@@ -173,6 +173,9 @@ struct tk_node {
     DBuf all_ids, all_offs;                    // on the root: the gathered result
     bool wire18 = false;                       // every id fits 18 bits
     bool loopback = false;                     // TK_NODE_FORCE_RCCL: also the root's own run travels through send / recv
+    bool d2d = false;                          // test builds only (TK_NODE_TEST_TRANSPORT): device-to-device copies stand in for ncclSend / ncclRecv
+    std::vector<hipEvent_t> ev_peer;           // d2d: the peer's payload is ready (recorded on its stream, awaited by the root's)
+    std::vector<uint64_t> last_shard_bytes, last_shard_ids;
     std::mutex mu;
     std::string err;
     float last_gather_ms = 0.f, last_kernels_ms = 0.f;
@@ -205,6 +208,8 @@ extern "C" void tk_node_destroy(tk_node* nd) {
     for (HBuf& h : nd->rel) h.release();
     for (int i = 0; i < (int)nd->comm.size(); ++i)
         if (nd->comm[i]) (void)g_rccl.CommDestroy(nd->comm[i]);
+    for (hipEvent_t e : nd->ev_peer)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < nd->n; ++i) {
         if (i < (int)nd->devs.size()) (void)hipSetDevice(nd->devs[i]);
         if (i < (int)nd->in_bytes.size()) { nd->in_bytes[i].release(); nd->in_offs[i].release(); nd->packed[i].release(); nd->stage[i].release(); }
@@ -224,13 +229,21 @@ extern "C" int tk_node_create(const uint8_t* token_bytes, const uint32_t* token_
     if (!out_node) { g_node_tls_err = "out_node is NULL"; return TK_ERR_INVALID_ARG; }
     *out_node = nullptr;
     if (!device_ids || n_devices < 1 || n_devices > 64) { g_node_tls_err = "n_devices must be 1..64"; return TK_ERR_INVALID_ARG; }
-    for (int i = 0; i < n_devices; ++i)
+    bool d2d = false;
+#ifdef TK_NODE_TEST_TRANSPORT
+    // Test builds only (`make ablate`; never in the shipped library): TK_NODE_TRANSPORT=d2d runs the WHOLE N > 1 branch -- shards,
+    // worker threads, 18-bit packing, staging, unpacking, offset rebase -- with stream-ordered device-to-device copies standing
+    // in for ncclSend / ncclRecv, and lets device ids repeat: N contexts on ONE GPU.  What it cannot show is the link itself.
+    if (const char* tr = getenv("TK_NODE_TRANSPORT")) d2d = strcmp(tr, "d2d") == 0;
+#endif
+    for (int i = 0; i < n_devices && !d2d; ++i)
         for (int j = 0; j < i; ++j)
             if (device_ids[i] == device_ids[j]) {
                 g_node_tls_err = "device " + std::to_string(device_ids[i]) + " is listed twice: one context per GPU";
                 return TK_ERR_INVALID_ARG;
             }
     tk_node* nd = new tk_node();
+    nd->d2d = d2d;
     nd->n = n_devices;
     nd->devs.assign(device_ids, device_ids + n_devices);
     nd->ctx.assign(n_devices, nullptr);
@@ -253,7 +266,12 @@ extern "C" int tk_node_create(const uint8_t* token_bytes, const uint32_t* token_
     nd->loopback = getenv("TK_NODE_FORCE_RCCL") != nullptr;
     if (hipSetDevice(device_ids[0]) != hipSuccess || hipEventCreate(&nd->ev0) != hipSuccess || hipEventCreate(&nd->ev1) != hipSuccess)
         return fail(TK_ERR_RUNTIME, "hipEventCreate failed");
-    if (n_devices > 1 || nd->loopback) {
+    if (nd->d2d) {
+        nd->ev_peer.assign(n_devices, nullptr);
+        for (int i = 0; i < n_devices; ++i)
+            if (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&nd->ev_peer[i], hipEventDisableTiming) != hipSuccess)
+                return fail(TK_ERR_RUNTIME, "hipEventCreate failed");
+    } else if (n_devices > 1 || nd->loopback) {
         std::lock_guard<std::mutex> lock(g_rccl_mu);
         std::string e;
         if (!g_rccl.open(e)) return fail(TK_ERR_RUNTIME, e);
@@ -339,7 +357,19 @@ static int node_encode(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_of
         for (int k = 0; k < n; ++k) nd->workers[k]->wait();
     }
     for (int k = 0; k < n; ++k)
-        if (sh[k].rc != TK_OK) { nd->err = "device " + std::to_string(nd->devs[k]) + ": " + sh[k].err; return sh[k].rc; }
+        if (sh[k].rc != TK_OK) {
+            // a device failed: copies from the caller's buffer and from the pinned offset staging may still be queued on the other
+            // devices' streams -- nothing returns to the caller, who may free or reuse that memory, before they have drained
+            for (int j = 0; j < n; ++j) {
+                (void)hipSetDevice(nd->devs[j]);
+                (void)hipStreamSynchronize(nd->stream[j]);
+            }
+            (void)hipSetDevice(nd->devs[0]);
+            nd->err = "device " + std::to_string(nd->devs[k]) + ": " + sh[k].err;
+            return sh[k].rc;
+        }
+    nd->last_shard_bytes.assign(n, 0); nd->last_shard_ids.assign(n, 0);
+    for (int k = 0; k < n; ++k) { nd->last_shard_bytes[k] = sh[k].n_bytes; nd->last_shard_ids[k] = sh[k].n_ids; }
 
     // ---- the one exchange: every run's ids (+ per-document offsets) to the root device, document order ----
     uint64_t total = 0;
@@ -354,7 +384,7 @@ static int node_encode(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_of
     hipStream_t rs = nd->stream[0];
     NODE_HIP(nd, hipEventRecord(nd->ev0, rs));
     NODE_HIP(nd, hipMemsetAsync(offs, 0, 8, rs));
-    const bool use_rccl = !nd->comm.empty();
+    const bool use_rccl = !nd->comm.empty() || nd->d2d;
     if (!(use_rccl && nd->loopback)) {
         // the root's own run: device-to-device inside the root
         if (sh[0].n_ids) NODE_HIP(nd, hipMemcpyAsync(ids, sh[0].d_ids, sh[0].n_ids * 4, hipMemcpyDeviceToDevice, rs));
@@ -364,30 +394,44 @@ static int node_encode(tk_node* nd, const uint8_t* bytes, const uint64_t* doc_of
     if (use_rccl) {
         for (int k = nd->loopback ? 0 : 1; k < n; ++k)
             if (nd->wire18 && sh[k].n_ids) NODE_HIP(nd, nd->stage[k].reserve(tk_ids18_bytes(sh[k].n_ids)));
-        NODE_NCCL(nd, g_rccl.GroupStart());
+        // one transfer peer k -> root: ncclSend on the peer's communicator and stream + ncclRecv on the root's (all of them inside
+        // ONE group: seven links side by side), or -- test transport -- a device-to-device copy on the root's stream behind an
+        // event on the peer's
+        auto xfer = [&](int k, const void* src, void* dst, size_t count, ncclDataType_t ty, size_t elem) -> int {
+            if (nd->d2d) {
+                NODE_HIP(nd, hipMemcpyAsync(dst, src, count * elem, hipMemcpyDeviceToDevice, rs));
+                return TK_OK;
+            }
+            NODE_NCCL(nd, g_rccl.Send(src, count, ty, 0, nd->comm[k], nd->stream[k]));
+            NODE_NCCL(nd, g_rccl.Recv(dst, count, ty, k, nd->comm[0], rs));
+            return TK_OK;
+        };
+        if (nd->d2d) {
+            for (int k = nd->loopback ? 0 : 1; k < n; ++k) {
+                NODE_HIP(nd, hipSetDevice(nd->devs[k]));
+                NODE_HIP(nd, hipEventRecord(nd->ev_peer[k], nd->stream[k]));
+                NODE_HIP(nd, hipSetDevice(nd->devs[0]));
+                NODE_HIP(nd, hipStreamWaitEvent(rs, nd->ev_peer[k], 0));
+            }
+        } else {
+            NODE_NCCL(nd, g_rccl.GroupStart());
+        }
         auto post = [&]() -> int {                                 // (a failure in here must still close the group)
             for (int k = nd->loopback ? 0 : 1; k < n; ++k) {
                 const Shard& s = sh[k];
                 const uint64_t nd_k = s.d1 - s.d0;
+                int rc = TK_OK;
                 if (s.n_ids) {
-                    if (nd->wire18) {
-                        const size_t nb = tk_ids18_bytes(s.n_ids);
-                        NODE_NCCL(nd, g_rccl.Send(nd->packed[k].p, nb, ncclUint8, 0, nd->comm[k], nd->stream[k]));
-                        NODE_NCCL(nd, g_rccl.Recv(nd->stage[k].p, nb, ncclUint8, k, nd->comm[0], rs));
-                    } else {
-                        NODE_NCCL(nd, g_rccl.Send(s.d_ids, s.n_ids, ncclUint32, 0, nd->comm[k], nd->stream[k]));
-                        NODE_NCCL(nd, g_rccl.Recv(ids + base[k], s.n_ids, ncclUint32, k, nd->comm[0], rs));
-                    }
+                    if (nd->wire18) rc = xfer(k, nd->packed[k].p, nd->stage[k].p, tk_ids18_bytes(s.n_ids), ncclUint8, 1);
+                    else rc = xfer(k, s.d_ids, ids + base[k], s.n_ids, ncclUint32, 4);
+                    if (rc != TK_OK) return rc;
                 }
-                if (nd_k) {
-                    NODE_NCCL(nd, g_rccl.Send((const uint64_t*)s.d_oo + 1, nd_k, ncclUint64, 0, nd->comm[k], nd->stream[k]));
-                    NODE_NCCL(nd, g_rccl.Recv(offs + s.d0 + 1, nd_k, ncclUint64, k, nd->comm[0], rs));
-                }
+                if (nd_k && (rc = xfer(k, (const uint64_t*)s.d_oo + 1, offs + s.d0 + 1, nd_k, ncclUint64, 8)) != TK_OK) return rc;
             }
             return TK_OK;
         };
         const int prc = post();
-        const ncclResult_t ge = g_rccl.GroupEnd();
+        const ncclResult_t ge = nd->d2d ? ncclSuccess : g_rccl.GroupEnd();
         if (prc != TK_OK) return prc;
         if (ge != ncclSuccess) { nd->err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge); return TK_ERR_RUNTIME; }
         for (int k = nd->loopback ? 0 : 1; k < n; ++k) {
@@ -477,3 +521,12 @@ extern "C" int tk_node_last_timing(const tk_node* nd, float* kernels_ms_max, flo
 }
 
 extern "C" int tk_node_n_devices(const tk_node* nd) { return nd ? nd->n : 0; }
+
+extern "C" int tk_node_last_shards(const tk_node* nd, uint64_t* shard_bytes, uint64_t* shard_ids, int cap) {
+    if (!nd) return TK_ERR_INVALID_ARG;
+    for (int k = 0; k < cap && k < (int)nd->last_shard_bytes.size(); ++k) {
+        if (shard_bytes) shard_bytes[k] = nd->last_shard_bytes[k];
+        if (shard_ids) shard_ids[k] = nd->last_shard_ids[k];
+    }
+    return (int)nd->last_shard_bytes.size();
+}

@@ -111,3 +111,33 @@ def test_node_api_single_device_and_rccl_loopback(tk, test_vocab, monkeypatch):
         nd.close()
     with pytest.raises(tk.TokenizerError):
         tk.Node(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], devices=(0, 0))
+
+
+def test_node_n_devices_on_one_gpu(tmp_path):
+    """csrc/tk_node.cpp's N > 1 branch (it has only ever met a self-loop: this pool hands out one GPU) with N = 2, 3, 8 contexts on
+    GPU 0 and the test transport of the development build -- ascii, zipf, a batch whose runs are mostly empty, no documents at all;
+    bit-exact against the oracle, byte balance asserted (tests/node_d2d_worker.py)."""
+    lib = os.path.join(ROOT, "tekken-rs_amd", "libtekken_hip_ablate.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tekken-rs_amd"), "ablate"])
+    out = str(tmp_path / "node_d2d.txt")
+    env = dict(os.environ, TK_HIP_LIB=lib, TK_NODE_TRANSPORT="d2d")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "node_d2d_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert open(out).read() == "ok", open(out).read()
+
+
+def test_shipped_library_has_no_test_transport():
+    """TK_NODE_TRANSPORT is read by the development build only: the shipped library refuses a device listed twice whatever the
+    environment says."""
+    import importlib
+    tk = importlib.import_module("tekken-rs_amd")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    v = helpers.small_trained_vocab()
+    os.environ["TK_NODE_TRANSPORT"] = "d2d"
+    try:
+        with pytest.raises(tk.TokenizerError):
+            tk.Node(v["tokens"], v["num_special"], v["bos"], v["eos"], devices=(0, 0))
+    finally:
+        del os.environ["TK_NODE_TRANSPORT"]

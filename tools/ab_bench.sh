@@ -2,13 +2,11 @@
 # same-box A/B of prebuilt library variants on the plain C2 bench line (no profiler): tools/ab_bench.sh libA.so libB.so ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-cp tekken-rs_amd/libtekken_hip.so gpurun_out/lib_keep.so
 for rep in 1 2 3; do
   for v in "$@"; do
-    cp $v tekken-rs_amd/libtekken_hip.so
+    export TK_HIP_LIB=$R/$v   # (the shipped library is never overwritten: tekken-rs_amd/__init__.py loads what TK_HIP_LIB names)
     timeout -k 10 200 python bench.py --steps 40 --warmup 5 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'rep', $rep, 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'])" || exit 1
   done
 done
-cp gpurun_out/lib_keep.so tekken-rs_amd/libtekken_hip.so

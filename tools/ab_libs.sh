@@ -3,12 +3,10 @@
 # runs tools/quick_merge.sh (kernel trace of the C3 and C2 shapes) once per variant, twice round-robin
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-cp tekken-rs_amd/libtekken_hip.so gpurun_out/lib_keep.so
 for rep in 1 2; do
   for v in "$@"; do
-    cp $v tekken-rs_amd/libtekken_hip.so
+    export TK_HIP_LIB=$R/$v   # (the shipped library is never overwritten: tekken-rs_amd/__init__.py loads what TK_HIP_LIB names)
     echo "== $v (rep $rep)"
     bash tools/quick_merge.sh | grep "^c2" || exit 1
   done
 done
-cp gpurun_out/lib_keep.so tekken-rs_amd/libtekken_hip.so

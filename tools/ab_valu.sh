@@ -3,10 +3,9 @@
 # instruction-count work on the flat kernel): tools/ab_valu.sh "<bench args>" libA.so libB.so ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 args="$1"; shift
-cp $R/tekken-rs_amd/libtekken_hip.so $R/gpurun_out/lib_keep.so
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  cp $R/$v $R/tekken-rs_amd/libtekken_hip.so
+  export TK_HIP_LIB=$R/$v   # (the shipped library is never overwritten: tekken-rs_amd/__init__.py loads what TK_HIP_LIB names)
   tag=$(basename $v .so)
   rm -rf $R/gpurun_out/abv_$tag
   timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/abv_$tag -o v -- python3 $R/bench.py $args --steps 2 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > $R/gpurun_out/abv_$tag.log 2>&1 || { tail -5 $R/gpurun_out/abv_$tag.log; exit 1; }
@@ -21,4 +20,3 @@ for r in csv.DictReader(open(f)):
 print(sys.argv[2], {k: round(sum(v) / len(v) / (1 if k == "ms" else 1e6), 3) for k, v in sorted(acc.items())})
 PY
 done
-cp $R/gpurun_out/lib_keep.so $R/tekken-rs_amd/libtekken_hip.so

@@ -155,3 +155,51 @@ def test_tekken_pattern_live_against_python_regex():
         s = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 16)))
         exp = [len(s[:m.start()].encode()) for m in R.finditer(s)]
         assert tk_oracle.split_tekken(s.encode()) == exp, repr(s)
+
+
+def test_corpora_and_golden_texts_avoid_unicode_drift():
+    """SURVEY 7.3-3 / trap T11: the reference's regex-syntax (its Unicode tables) is unpinned, ours are `regex`'s (Unicode 17 in this image).
+    The only code points on which the two splits could differ without either being wrong are those whose L / N class changed after the
+    reference's version -- bounded here by everything that differs from Unicode 13.0 (python's unicodedata), listed in
+    tests/golden/unicode_drift.json by tools/unicode_drift.py.  No bench corpus alphabet, no golden text and no test alphabet may use
+    one of them: every parity claim in this repository is then independent of the Unicode version."""
+    import json
+    import os
+    import numpy as np
+    import corpus
+    import helpers
+    root = os.path.dirname(os.path.abspath(__file__))
+    drift = json.load(open(os.path.join(root, "golden", "unicode_drift.json")))
+    assert drift["unicodedata_version"].startswith("13.") and drift["code_points"] > 0
+    bad = np.zeros(0x110000, bool)
+    for lo, hi, _, _ in drift["ranges_lo_hi_class13_classNow"]:
+        bad[lo:hi + 1] = True
+
+    def check(text, what):
+        cps = np.frombuffer(text.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+        hit = np.unique(cps[bad[np.minimum(cps, 0x10FFFF)]])
+        assert len(hit) == 0, "%s uses code points whose class depends on the Unicode version: %s" % (what, [hex(int(c)) for c in hit[:8]])
+
+    for kind, n, dl in (("ascii", 2000, 512), ("mixed", 4000, 2048), ("zipf", 3000, 0)):
+        data, offs = corpus.generate(kind, n, dl, seed=corpus.BASE_SEED + 2)
+        check(data.tobytes().decode("utf-8"), "the %s bench corpus" % kind)
+    check(" ".join(corpus.words()), "the corpus word list")
+
+    def strings(x):
+        if isinstance(x, str):
+            yield x
+        elif isinstance(x, dict):
+            for k, v in x.items():
+                yield from strings(k)
+                yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+
+    gdir = os.path.join(root, "golden")
+    for name in sorted(os.listdir(gdir)):
+        if name.endswith(".json") and name != "unicode_drift.json":
+            for s in strings(json.load(open(os.path.join(gdir, name)))):
+                check(s, "tests/golden/" + name)
+    for d in list(helpers.EDGE_DOCS) + helpers.random_unicode_docs(200):
+        check(d.decode("utf-8", "replace"), "the test alphabets of tests/helpers.py")

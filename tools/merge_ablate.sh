@@ -1,6 +1,6 @@
 #!/bin/bash
-# needs the development build with the ablation hooks: make -C tekken-rs_amd ablate && cp tekken-rs_amd/libtekken_hip_ablate.so tekken-rs_amd/libtekken_hip.so
-# (rebuild the shipped library afterwards: make -C tekken-rs_amd -B libtekken_hip.so)
+# needs the development build with the ablation hooks (make -C tekken-rs_amd ablate): selected through TK_HIP_LIB, the shipped library stays
+export TK_HIP_LIB=${GRAFT_REPO_ROOT:-$(pwd)}/tekken-rs_amd/libtekken_hip_ablate.so
 # timing-only ablations of the merge kernels (needs a build with -DTKM_ABLATE): tools/merge_ablate.sh "0 256 512 ..." [bench args]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 vals=${1:-"0 256 512 768 1024 2048 3840"}

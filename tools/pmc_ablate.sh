@@ -1,6 +1,6 @@
 #!/bin/bash
-# needs the development build with the ablation hooks: make -C tekken-rs_amd ablate && cp tekken-rs_amd/libtekken_hip_ablate.so tekken-rs_amd/libtekken_hip.so
-# (rebuild the shipped library afterwards: make -C tekken-rs_amd -B libtekken_hip.so)
+# needs the development build with the ablation hooks (make -C tekken-rs_amd ablate): selected through TK_HIP_LIB, the shipped library stays
+export TK_HIP_LIB=${GRAFT_REPO_ROOT:-$(pwd)}/tekken-rs_amd/libtekken_hip_ablate.so
 # VALU / SALU / LDS instruction counts of tk_flat_kernel per timing ablation (TK_DEBUG_ABLATE): the difference between
 # two ablations is the instruction count of the phase between them.   tools/pmc_ablate.sh  -> gpurun_out/pmc_abl_<n>/
 root=${GRAFT_REPO_ROOT:-$(pwd)}

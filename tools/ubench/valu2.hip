@@ -1,0 +1,112 @@
+// Micro-benchmark 4 (round 4): what a wave-instruction of each class tk_flat_kernel is made of costs a SIMD, as
+// a function of the waves that share it.  Kernels of >= 1 ms, clocked with s_memtime INSIDE the kernel (no launch overhead, no
+// assumed clock: the tick is the shader cycle, MI355X_MICROARCH.md "s_memtime tick"), 1 / 2 / 4 / 7 waves per SIMD (blocks of 256
+// threads = one wave per SIMD, k blocks per CU; 7 is what tk_flat_kernel runs at).  Reported: cycles per wave-instruction PER SIMD
+// = elapsed cycles of a wave / (its instructions x waves on the SIMD).  The guide says 2 (SIMD-32: a wave64 instruction issues
+// over 2 cycles) once enough waves share the SIMD, 4 for one wave alone.
+//   hipcc --offload-arch=gfx950 -O3 -o valu2 tools/ubench/valu2.hip && ./valu2 > profiles/ubench/r04_valu2.json
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#define REP8(x) x x x x x x x x
+// every body is 4 instructions on independent registers; REP8 => 32 instructions per iteration
+#define KERNEL(name, body)                                                                         \
+    __global__ __launch_bounds__(256) void name(uint64_t* ticks, uint32_t* sink, int iters, uint32_t s) { \
+        uint32_t a = threadIdx.x * 2654435761u + s, b = a ^ 0x9E3779B9u, c = a + 77u, d = b + 99u; \
+        uint32_t e = a * 3u | 1u, f = b * 5u;                                                      \
+        uint64_t A = a, B = b, C = c, D = d;                                                       \
+        const uint64_t r0 = __builtin_amdgcn_s_memrealtime();                                      \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                          \
+        for (int i = 0; i < iters; ++i) { REP8(body) }                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)");                                                      \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                          \
+        const uint64_t r1 = __builtin_amdgcn_s_memrealtime();                                      \
+        if ((threadIdx.x & 63u) == 0u) {                                                           \
+            const uint32_t w = (blockIdx.x * 256u + threadIdx.x) >> 6;                             \
+            ticks[3u * w] = t1 - t0; ticks[3u * w + 1u] = r0; ticks[3u * w + 2u] = r1;             \
+        }                                                                                          \
+        if ((a ^ b ^ c ^ d ^ e ^ f ^ (uint32_t)(A ^ B ^ C ^ D)) == 0x12345u) sink[0] = a;          \
+    }
+
+KERNEL(k_alu, asm volatile("v_add_u32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_and_or_b32 %2, %2, %4, %0\n v_lshlrev_b32 %3, 3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_bitop3, asm volatile("v_bitop3_b32 %0, %0, %4, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %2 bitop3:0xe8\n v_bitop3_b32 %2, %2, %4, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %0 bitop3:0xca" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_dpp_mov, asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+KERNEL(k_dpp_add, asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %0, %1, 13\n v_alignbit_b32 %1, %1, %2, 7\n v_alignbyte_b32 %2, %2, %3, %4\n v_alignbyte_b32 %3, %3, %0, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_perm, asm volatile("v_perm_b32 %0, %0, %4, %1\n v_perm_b32 %1, %1, %4, %2\n v_perm_b32 %2, %2, %4, %3\n v_perm_b32 %3, %3, %4, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_bcnt, asm volatile("v_bcnt_u32_b32 %0, %0, %4\n v_mbcnt_lo_u32_b32 %1, %4, %1\n v_mbcnt_hi_u32_b32 %2, %4, %2\n v_ffbl_b32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_cmp_cndmask, asm volatile("v_cmp_gt_u32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_lt_u32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "vcc");)
+KERNEL(k_cmp_sgpr, asm volatile("v_cmp_gt_u32 s[20:21], %0, %4\n v_cmp_ne_u32 s[22:23], %1, %4\n v_cmp_lt_u32 s[24:25], %2, %4\n v_cmp_eq_u32 s[26:27], %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+KERNEL(k_mul_lo, asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_mad_u64, asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "v"(e), "v"(f) : "vcc");)
+KERNEL(k_shift64, asm volatile("v_lshlrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshl_add_u64 %2, %2, 1, %0\n v_lshl_add_u64 %3, %3, 2, %1" : "+v"(A), "+v"(B), "+v"(C), "+v"(D));)
+KERNEL(k_readlane, asm volatile("v_readlane_b32 s20, %0, 3\n v_readfirstlane_b32 s21, %1\n v_readlane_b32 s22, %2, 5\n v_readfirstlane_b32 s23, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "s20", "s21", "s22", "s23");)
+KERNEL(k_min3, asm volatile("v_min3_u32 %0, %0, %4, %1\n v_min3_u32 %1, %1, %4, %2\n v_max3_u32 %2, %2, %4, %3\n v_min_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_sdwa, asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_and_b32_sdwa %1, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n v_xor_b32_sdwa %2, %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_and_b32_sdwa %3, %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+// two independent streams in ONE wave against one dependent chain: what interleaving a second chunk into a wave could buy
+KERNEL(k_dep_chain, asm volatile("v_add_u32 %0, %0, %4\n v_xor_b32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_xor_b32 %0, %0, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+
+typedef void (*kern_t)(uint64_t*, uint32_t*, int, uint32_t);
+struct Row { const char* name; kern_t k; };
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    uint64_t* ticks;
+    uint32_t* sink;
+    hipMalloc(&ticks, sizeof(uint64_t) * cus * 8 * 4 * 3);
+    hipMalloc(&sink, 64);
+    const Row rows[] = {{"alu32 (add / xor / and_or / shift)", k_alu}, {"v_bitop3_b32", k_bitop3}, {"v_mov_b32_dpp (wave_shr / wave_shl)", k_dpp_mov},
+                        {"v_add_u32_dpp (row_shr / row_bcast)", k_dpp_add}, {"v_alignbit_b32 / v_alignbyte_b32", k_alignbit}, {"v_perm_b32", k_perm},
+                        {"v_bcnt / v_mbcnt / v_ffbl", k_bcnt}, {"v_cmp (vcc) + v_cndmask", k_cmp_cndmask}, {"v_cmp -> sgpr pair", k_cmp_sgpr},
+                        {"v_mul_lo_u32", k_mul_lo}, {"v_mad_u64_u32", k_mad_u64}, {"64-bit shift / v_lshl_add_u64", k_shift64},
+                        {"v_readlane / v_readfirstlane", k_readlane}, {"v_min3 / v_max3 / v_min", k_min3}, {"sdwa", k_sdwa},
+                        {"dependent chain (one register)", k_dep_chain}};
+    const int occ[] = {1, 2, 4, 7};
+    const int iters = 40000;                        // 1.28 M wave-instructions per wave: >= 1 ms even at 2 cycles each
+    printf("{\n \"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"instructions_per_wave\": %d,\n", p.gcnArchName, cus, iters, iters * 32);
+    printf(" \"unit\": \"shader cycles (s_memtime) per wave-instruction per SIMD = wave's elapsed cycles / (its instructions x waves per SIMD)\",\n \"classes\": {\n");
+    std::vector<uint64_t> h(cus * 8 * 4 * 3), tk(cus * 8 * 4);
+    for (size_t r = 0; r < sizeof(rows) / sizeof(rows[0]); ++r) {
+        printf("  \"%s\": {", rows[r].name);
+        for (int oi = 0; oi < 4; ++oi) {
+            const int k = occ[oi], blocks = cus * k;
+            hipLaunchKernelGGL(rows[r].k, dim3(blocks), dim3(256), 0, 0, ticks, sink, 64, 1u);          // warm the instruction cache
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(rows[r].k, dim3(blocks), dim3(256), 0, 0, ticks, sink, iters, 2u);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h.data(), ticks, sizeof(uint64_t) * blocks * 4 * 3, hipMemcpyDeviceToHost);
+            // s_memrealtime is the constant 100 MHz reference: the shader clock under THIS load = s_memtime ticks per reference tick; and
+            // how much of the kernel's span a wave was alive tells whether the k blocks per CU really ran side by side
+            const int nw = blocks * 4;
+            uint64_t rmin = ~0ull, rmax = 0;
+            double life = 0, ghz = 0;
+            for (int w = 0; w < nw; ++w) {
+                tk[w] = h[3 * w];
+                rmin = std::min(rmin, h[3 * w + 1]); rmax = std::max(rmax, h[3 * w + 2]);
+                life += (double)(h[3 * w + 2] - h[3 * w + 1]);
+                ghz += (double)h[3 * w] / (double)(h[3 * w + 2] - h[3 * w + 1]) * 0.1;
+            }
+            std::sort(tk.begin(), tk.begin() + nw);
+            const double med = (double)tk[nw / 2], n = (double)iters * 32.0, conc = life / nw / (double)(rmax - rmin);
+            // clk: per SIMD, with the waves that were actually alive together (k x concurrency)
+            printf("%s\"%d\": {\"clk\": %.3f, \"clk_if_all_k_resident\": %.3f, \"resident_share\": %.3f, \"kernel_ms\": %.3f, \"shader_GHz\": %.3f}", oi ? ", " : "", k,
+                   med / (n * k * conc), med / (n * k), conc, ms, ghz / nw);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+        printf("}%s\n", r + 1 < sizeof(rows) / sizeof(rows[0]) ? "," : "");
+    }
+    printf(" }\n}\n");
+    return 0;
+}

@@ -356,11 +356,15 @@ def main():
                 traffic_info = {"traffic_pipeline": tj.get("pipeline_bytes_per_step"), "traffic_measured_at": tj.get("git"),
                                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this shape)" % tname}
                 if tj.get("tk_flat_kernel_valu_floor_ms"):
-                    # the bound that actually applies to the dominant kernel: VALU issue.  floor = VALU wave-instructions per launch
-                    # (SQ_INSTS_VALU, PMC pass at the stamped commit) x 4 clocks / (1 024 SIMDs x 2.4 GHz); frac = floor / measured
+                    # floor = SQ_INSTS_VALU (PMC pass at the stamped commit) x the measured issue cost of the kernel's instruction mix
+                    # (tools/valu_mix.py, profiles/ubench/r04_valu2.json) / (1 024 SIMDs x the measured shader clock); frac = floor / measured.
+                    # floor_ms_at_2clk: every instruction at the guide's 2 cycles -- the kernel cannot be faster than that either
                     bound_by = {"unit": "valu", "insts_per_launch": tj["tk_flat_kernel_valu_insts_per_launch"],
+                                "clk_per_instruction_mix": tj.get("tk_flat_kernel_valu_clk_mix", 4.0),
                                 "floor_ms": round(tj["tk_flat_kernel_valu_floor_ms"], 4),
-                                "frac": round(tj["tk_flat_kernel_valu_floor_ms"] / k_ms, 4), "measured_at": tj.get("git")}
+                                "frac": round(tj["tk_flat_kernel_valu_floor_ms"] / k_ms, 4),
+                                "floor_ms_at_2clk": round(tj.get("tk_flat_kernel_valu_floor_ms_at_2clk", 0.0), 4),
+                                "measured_at": tj.get("git")}
             except Exception:  # noqa: BLE001
                 traffic = None
         cfg1, cfgN = CONFIG_OF_KIND[args.kind]

@@ -145,10 +145,24 @@ def summarize(tag, sfx, bench, tpath, sqpath, go):
         res["pipeline_bytes_per_step"] = sum(v["read_upper"] + v["write"] for v in per_kernel.values())
         if bench:
             res["pipeline_traffic_over_algorithmic"] = res["pipeline_bytes_per_step"] / bench["roofline"]["bytes_alg_per_launch"]
-    # the arithmetic floor of the dominant kernel: VALU wave-instructions x 4 clocks over 1 024 SIMDs at 2.4 GHz
+    # the VALU-issue floor of the dominant kernel: dynamic VALU wave-instructions (SQ_INSTS_VALU) x the issue cost of the kernel's
+    # instruction mix (tools/valu_mix.py: static mix x the per-class cycles tools/ubench/valu2.hip measured at 4..7 waves per SIMD --
+    # 2 for 32-bit encoded two-operand ALU instructions, the guide's SIMD-32 figure, ~4.1-4.8 for compares, DPP, three-operand and
+    # 64-bit encoded ones) over 1 024 SIMDs at the shader clock the micro-benchmark ran at.  The guide's 2 cycles for EVERY
+    # instruction is the lower bound beside it.
     if "SQ_INSTS_VALU" in fk:
         res["tk_flat_kernel_valu_insts_per_launch"] = fk["SQ_INSTS_VALU"]
-        res["tk_flat_kernel_valu_floor_ms"] = fk["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.4e9 * 1e3
+        clk_mix, ghz, src = 4.0, 2.4, "assumed 4 cycles at 2.4 GHz (profiles/r04_valu_mix.json missing)"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_valu_mix.json")) as f:
+                vm = json.load(f)["issue_cost"]
+            clk_mix, ghz, src = vm["clk_mix"], vm["shader_GHz"], "profiles/r04_valu_mix.json (tools/valu_mix.py + profiles/ubench/r04_valu2.json)"
+        except Exception:  # noqa: BLE001
+            pass
+        res["tk_flat_kernel_valu_clk_mix"] = clk_mix
+        res["tk_flat_kernel_valu_clk_source"] = src
+        res["tk_flat_kernel_valu_floor_ms"] = fk["SQ_INSTS_VALU"] * clk_mix / 1024.0 / (ghz * 1e9) * 1e3
+        res["tk_flat_kernel_valu_floor_ms_at_2clk"] = fk["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (ghz * 1e9) * 1e3
     with open(tpath, "w") as f:
         json.dump(res, f, indent=1)
     sq = {k: {c: v for c, v in mean.get(k, {}).items() if c not in ("FETCH_SIZE", "WRITE_SIZE")} for k in KERNELS[:4]}

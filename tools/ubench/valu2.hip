@@ -33,7 +33,8 @@
         if ((a ^ b ^ c ^ d ^ e ^ f ^ (uint32_t)(A ^ B ^ C ^ D)) == 0x12345u) sink[0] = a;          \
     }
 
-KERNEL(k_alu, asm volatile("v_add_u32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_and_or_b32 %2, %2, %4, %0\n v_lshlrev_b32 %3, 3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_alu, asm volatile("v_add_u32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_lshlrev_b32 %3, 3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_alu_vop3, asm volatile("v_and_or_b32 %0, %0, %4, %1\n v_add3_u32 %1, %1, %4, %2\n v_bfe_u32 %2, %2, 3, 11\n v_lshl_or_b32 %3, %3, 2, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_bitop3, asm volatile("v_bitop3_b32 %0, %0, %4, %1 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %2 bitop3:0xe8\n v_bitop3_b32 %2, %2, %4, %3 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %0 bitop3:0xca" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_dpp_mov, asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
 KERNEL(k_dpp_add, asm volatile("s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
@@ -51,6 +52,13 @@ KERNEL(k_sdwa, asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:
 // two independent streams in ONE wave against one dependent chain: what interleaving a second chunk into a wave could buy
 KERNEL(k_dep_chain, asm volatile("v_add_u32 %0, %0, %4\n v_xor_b32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_xor_b32 %0, %0, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 
+// the same instruction on 1 / 2 / 4 registers in turn: is the ~4 of the independent streams above a property of the SIMD or of reading
+// operands that are not forwarded from the instruction before?
+KERNEL(k_add_1reg, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_add_2reg, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_add_4reg, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_add_4reg_const, asm volatile("v_add_u32 %0, 7, %0\n v_add_u32 %1, 7, %1\n v_add_u32 %2, 7, %2\n v_add_u32 %3, 7, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+
 typedef void (*kern_t)(uint64_t*, uint32_t*, int, uint32_t);
 struct Row { const char* name; kern_t k; };
 
@@ -62,12 +70,13 @@ int main() {
     uint32_t* sink;
     hipMalloc(&ticks, sizeof(uint64_t) * cus * 8 * 4 * 3);
     hipMalloc(&sink, 64);
-    const Row rows[] = {{"alu32 (add / xor / and_or / shift)", k_alu}, {"v_bitop3_b32", k_bitop3}, {"v_mov_b32_dpp (wave_shr / wave_shl)", k_dpp_mov},
+    const Row rows[] = {{"alu32 (add / xor / and_or / shift)", k_alu}, {"alu32 three-operand (and_or / add3 / bfe / lshl_or: 64-bit encoding)", k_alu_vop3}, {"v_bitop3_b32", k_bitop3}, {"v_mov_b32_dpp (wave_shr / wave_shl)", k_dpp_mov},
                         {"v_add_u32_dpp (row_shr / row_bcast)", k_dpp_add}, {"v_alignbit_b32 / v_alignbyte_b32", k_alignbit}, {"v_perm_b32", k_perm},
                         {"v_bcnt / v_mbcnt / v_ffbl", k_bcnt}, {"v_cmp (vcc) + v_cndmask", k_cmp_cndmask}, {"v_cmp -> sgpr pair", k_cmp_sgpr},
                         {"v_mul_lo_u32", k_mul_lo}, {"v_mad_u64_u32", k_mad_u64}, {"64-bit shift / v_lshl_add_u64", k_shift64},
                         {"v_readlane / v_readfirstlane", k_readlane}, {"v_min3 / v_max3 / v_min", k_min3}, {"sdwa", k_sdwa},
-                        {"dependent chain (one register)", k_dep_chain}};
+                        {"dependent chain (one register)", k_dep_chain}, {"v_add_u32 on 1 register", k_add_1reg}, {"v_add_u32 on 2 registers in turn", k_add_2reg},
+                        {"v_add_u32 on 4 registers in turn", k_add_4reg}, {"v_add_u32 on 4 registers, inline constant", k_add_4reg_const}};
     const int occ[] = {1, 2, 4, 7};
     const int iters = 40000;                        // 1.28 M wave-instructions per wave: >= 1 ms even at 2 cycles each
     printf("{\n \"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"instructions_per_wave\": %d,\n", p.gcnArchName, cus, iters, iters * 32);

@@ -5,7 +5,7 @@ cd $R
 for rep in 1 2 3; do
   for v in "$@"; do
     export TK_HIP_LIB=$R/$v   # (the shipped library is never overwritten: tekken-rs_amd/__init__.py loads what TK_HIP_LIB names)
-    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 2>/dev/null | python -c "
+    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 --single-docs 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'rep', $rep, 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'])" || exit 1
   done

@@ -8,7 +8,7 @@ for v in "$@"; do
   export TK_HIP_LIB=$R/$v   # (the shipped library is never overwritten: tekken-rs_amd/__init__.py loads what TK_HIP_LIB names)
   tag=$(basename $v .so)
   rm -rf $R/gpurun_out/abv_$tag
-  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/abv_$tag -o v -- python3 $R/bench.py $args --steps 2 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > $R/gpurun_out/abv_$tag.log 2>&1 || { tail -5 $R/gpurun_out/abv_$tag.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/abv_$tag -o v -- python3 $R/bench.py $args --steps 2 --warmup 1 --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 --single-docs 0 > $R/gpurun_out/abv_$tag.log 2>&1 || { tail -5 $R/gpurun_out/abv_$tag.log; exit 1; }
   python3 - $R/gpurun_out/abv_$tag $tag <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]

@@ -7,7 +7,7 @@ vals=${1:-"0 256 512 768 1024 2048 3840"}
 shift
 cd /tmp && export TMPDIR=/tmp
 for v in $vals; do
-  TK_DEBUG_ABLATE=$v timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abl_$v -o a -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 "$@" > $R/gpurun_out/abl_$v.log 2>&1 || { tail -5 $R/gpurun_out/abl_$v.log; exit 1; }
+  TK_DEBUG_ABLATE=$v timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abl_$v -o a -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 "$@" > $R/gpurun_out/abl_$v.log 2>&1 || { tail -5 $R/gpurun_out/abl_$v.log; exit 1; }
   python3 - $R/gpurun_out/abl_$v/a_kernel_stats.csv $v <<'PY'
 import csv, sys
 rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(sys.argv[1]))}

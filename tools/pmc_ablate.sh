@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for ab in ${ABLATE_LIST:-16 8 1 64 128 2 0}; do
   export TK_DEBUG_ABLATE=$ab
   timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv \
-    -d $root/gpurun_out/pmc_abl_$ab -o abl -- python3 $root/bench.py ${BENCH_ARGS} --steps 2 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > $root/gpurun_out/pmc_abl_$ab.log 2>&1 || exit 1
+    -d $root/gpurun_out/pmc_abl_$ab -o abl -- python3 $root/bench.py ${BENCH_ARGS} --steps 2 --warmup 1 --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 --single-docs 0 > $root/gpurun_out/pmc_abl_$ab.log 2>&1 || exit 1
   python3 - $root/gpurun_out/pmc_abl_$ab $ab <<'PY'
 import csv, glob, sys, collections
 d, ab = sys.argv[1], sys.argv[2]

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}${sfx}_${name} -o $tag -- \
-    python3 $root/bench.py --steps 3 --warmup 1 --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 "${SHAPE[@]}" > $root/gpurun_out/pmc_${tag}${sfx}_${name}.log 2>&1 || return 1
+    python3 $root/bench.py --steps 3 --warmup 1 --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 --single-docs 0 "${SHAPE[@]}" > $root/gpurun_out/pmc_${tag}${sfx}_${name}.log 2>&1 || return 1
   echo "pass $name$sfx done"
 }
 SHAPE=("$@")

@@ -4,7 +4,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q > gpurun_out/quick_tests.log 2>&1 || { tail -30 gpurun_out/quick_tests.log; exit 1; }
 tail -1 gpurun_out/quick_tests.log
-timeout -k 10 200 python bench.py --cpu-passes 0 ${BENCH_ARGS} 2> gpurun_out/quick_bench.err | python -c "
+timeout -k 10 200 python bench.py --cpu-passes 0 --extra-legs none ${BENCH_ARGS} 2> gpurun_out/quick_bench.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']

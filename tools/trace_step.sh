@@ -4,7 +4,7 @@
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$tag -o $tag -- python3 $R/bench.py "$@" --cpu-passes 0 --decode-steps 0 --host-steps 0 --single-docs 0 > $R/gpurun_out/trace_$tag.log 2>&1 || { tail -20 $R/gpurun_out/trace_$tag.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace_$tag -o $tag -- python3 $R/bench.py "$@" --cpu-passes 0 --extra-legs none --decode-steps 0 --host-steps 0 --single-docs 0 > $R/gpurun_out/trace_$tag.log 2>&1 || { tail -20 $R/gpurun_out/trace_$tag.log; exit 1; }
 cd $R
 python3 - $tag <<'PY' | tee gpurun_out/trace_$tag\_timeline.txt
 import csv, sys, glob

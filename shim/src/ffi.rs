@@ -48,6 +48,15 @@ extern "C" {
     pub fn tk_encode_batch_device(ctx: *mut TkCtx, d_bytes: *const c_void, d_doc_offsets: *const c_void, n_docs: u64, n_bytes: u64,
                                   add_bos: c_int, add_eos: c_int, hip_stream: *mut c_void, d_ids: *mut *mut c_void,
                                   d_out_offsets: *mut *mut c_void, n_ids: *mut u64) -> c_int;
+    // the same with the checks tk_encode_batch makes for host callers, on the device: TK_CHECK_OFFSETS = 1, TK_CHECK_UTF8 = 2
+    pub fn tk_encode_batch_device_ex(ctx: *mut TkCtx, d_bytes: *const c_void, d_doc_offsets: *const c_void, n_docs: u64, n_bytes: u64,
+                                     add_bos: c_int, add_eos: c_int, checks: c_int, hip_stream: *mut c_void, d_ids: *mut *mut c_void,
+                                     d_out_offsets: *mut *mut c_void, n_ids: *mut u64) -> c_int;
+    // memo of merged pieces (round 4): a device table {unknown piece of 2..16 bytes -> its <= 4 ids}; never changes an id
+    pub fn tk_ctx_set_memo(ctx: *mut TkCtx, log2_entries: c_int, policy: c_int) -> c_int;
+    pub fn tk_ctx_memo_clear(ctx: *mut TkCtx) -> c_int;
+    pub fn tk_memo_stats(ctx: *const TkCtx, lookups_last: *mut u64, hits_last: *mut u64, lookups_total: *mut u64, hits_total: *mut u64,
+                         active_last: *mut c_int) -> c_int;
     pub fn tk_host_alloc(bytes: usize) -> *mut c_void;
     pub fn tk_host_free(p: *mut c_void);
     pub fn tk_encode_batch_pipelined(ctx: *mut TkCtx, bytes: *const u8, doc_offsets: *const u64, n_docs: u64, add_bos: c_int,
@@ -70,4 +79,6 @@ extern "C" {
     // caller-owned host buffers (tk_host_alloc: pinned -- nothing allocated, pinned or copied on the host per call)
     pub fn tk_node_encode_batch_pinned(node: *mut TkNode, bytes: *const u8, doc_offsets: *const u64, n_docs: u64, add_bos: c_int,
                                        add_eos: c_int, ids_out: *mut u32, ids_capacity: u64, offsets_out: *mut u64, n_ids_out: *mut u64) -> c_int;
+    // how the last batch was cut: text bytes and ids of every device's run
+    pub fn tk_node_last_shards(node: *const TkNode, shard_bytes: *mut u64, shard_ids: *mut u64, cap: c_int) -> c_int;
 }

@@ -80,6 +80,16 @@ impl HipEngine {
         Ok(Self { ctx })
     }
 
+    /// Memo of merged pieces: `log2_entries` 0 switches it off, 10..26 sizes the table (32-byte entries); `always` = no adaptive pause.
+    /// The table can change how long a call takes, never an id (an entry is the exact key and the exact merge result).
+    pub fn set_memo(&self, log2_entries: i32, always: bool) -> Result<(), HipError> {
+        let rc = unsafe { tk_ctx_set_memo(self.ctx, log2_entries as c_int, always as c_int) };
+        if rc != TK_OK {
+            return Err(map_err(rc, unsafe { tk_last_error(self.ctx) }));
+        }
+        Ok(())
+    }
+
     /// `Tekkenizer::encode` for ONE `&str` (the reference's own signature): no allocation inside the library, the ids land in
     /// a Vec sized for the worst case (one id per byte + BOS + EOS).
     pub fn encode(&self, text: &str, add_bos: bool, add_eos: bool) -> Result<Vec<u32>, HipError> {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(TKF_BLOCK) void tk_flat_firstdoc_kernel(const uint6
     for (uint64_t c = c_lo; c <= c_hi; ++c) first_doc[c] = (uint32_t)(d + 1);
 }
 
-template <int DBG, int MODE, int PAT = 0>
+template <int DBG, int MODE, int PAT = 0, int MEMO = 1>
 __device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_t* lds_all) {
     const int lane = wv_lane();
     // the wave number is wave-uniform: say so, and the chunk index and everything addressed by it stay in scalar registers
@@ -65,13 +65,18 @@ __device__ __forceinline__ void tk_flat_kernel_body(const TkFlatArgs& a, uint32_
         c_end = a.n_chunks * (label + 1) / 8;
         c_step = nb * (TKF_BLOCK / 64);
     }
-    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE, PAT>(a, c, lane, lds);
-    tk_flat_flush_memo_hits(a, lds, lane);
+    for (uint64_t c = c_begin; c < c_end; c += c_step) tk_flat_chunk<DBG, MODE, PAT, 0, MEMO>(a, c, lane, lds);
+    if (MEMO) tk_flat_flush_memo_hits(a, lds, lane);
 }
 
 __global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_kernel(TkFlatArgs a) {
     __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
-    tk_flat_kernel_body<0, 0>(a, lds_all);
+    tk_flat_kernel_body<0, 0, 0, 0>(a, lds_all);
+}
+// the same with the look-up in the memo of merged pieces (launched when the call uses the table: a.memo_tab != NULL)
+__global__ __launch_bounds__(TKF_BLOCK) TKF_OCC void tk_flat_memo_kernel(TkFlatArgs a) {
+    __shared__ uint32_t lds_all[(TKF_BLOCK / 64) * TKF_LDS_WORDS];
+    tk_flat_kernel_body<0, 0, 0, 1>(a, lds_all);
 }
 
 // the tables were built with the strong key hash (mode 1: the cheap one could not place the vocabulary)
@@ -487,6 +492,7 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     if (blocks > cap) blocks = cap;
     if (a.pattern == 1) hipLaunchKernelGGL(tk_flat_json_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_split_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else if (a.t.key_hash_mode == 0u && a.memo_tab) hipLaunchKernelGGL(tk_flat_memo_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     if (a.cut_list && a.pattern == 0) {

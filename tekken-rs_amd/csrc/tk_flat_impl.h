@@ -479,7 +479,10 @@ TK_DEV uint32_t tkf_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n)
 #define TKF_ABL(a, bit) false
 #endif
 
-template <int DBG, int MODE, int PAT = 0, int CUT = 0>
+// MEMO = 1: the look-up in the memo of merged pieces compiled in (step 6).  The production kernel exists in both forms: a call that
+// does not use the table (switched off, or paused by the policy: text with few unknown pieces) runs the MEMO = 0 instantiation, which
+// is the kernel without a single instruction of it (13 M of 326 M VALU wave-instructions per C2 launch, two VGPRs and a spill).
+template <int DBG, int MODE, int PAT = 0, int CUT = 0, int MEMO = 1>
 TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* lds) {
     const TkTablesView& t = a.t;
     const int64_t n = (int64_t)a.n_bytes;
@@ -1092,8 +1095,8 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             // key and the ids the merge gave it sit in a 32-byte entry (two loads, one round trip).  A hit reserves exactly its ids'
             // slots and stores them right here: no queue entry, no holes, nothing for the merge kernel to do.  The entry is a pure
             // function of the bytes (of a fragment's too: fragments take the pure merge), so a hit can never change an id.
-            const uint64_t mbase = (uint64_t)wv_first(lds[TKF_L_MEMO + 0]) | ((uint64_t)wv_first(lds[TKF_L_MEMO + 1]) << 32);
-            if (mbase != 0ull) {
+            const uint64_t mbase = MEMO ? (uint64_t)wv_first(lds[TKF_L_MEMO + 0]) | ((uint64_t)wv_first(lds[TKF_L_MEMO + 1]) << 32) : 0ull;
+            if (MEMO && mbase != 0ull) {
                 if (miss && len <= 16u) {
                     const uint32_t ms = tk_memo_slot(h) & lds[TKF_L_MEMO + 2];
                     const tk_u32x4* me = reinterpret_cast<const tk_u32x4*>(wv_global_ptr(mbase) + ((uint64_t)ms << 5));
@@ -1124,7 +1127,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 slot += tkf_scan_excl(miss ? res - 1u : 0u, lane, &tot);
                 E += tot;
             }
-            const bool qmiss = miss && !mhit;               // what is left for the merge kernels
+            const bool qmiss = MEMO ? miss && !mhit : miss; // what is left for the merge kernels
             const uint64_t QB = wv_ballot(qmiss);
             if (QB == 0ull) {
             } else if (wv_ballot(qmiss && len > 8u) == 0ull) {
@@ -1150,7 +1153,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             list[idx] = (uint16_t)slot;                     // step 7 looks the slot of a document start up here
             if (!miss && !TKF_ABL(a, 4)) tmp[slot] = r + t.num_special;
         }
-        if (mhit) {                                         // the ids of the memo entry
+        if (MEMO && mhit) {                                 // the ids of the memo entry
             tmp[slot] = tk_memo_id(mv0, mv1, mv2, 0u) + t.num_special;
             if (res > 1u) tmp[slot + 1u] = tk_memo_id(mv0, mv1, mv2, 1u) + t.num_special;
             if (res > 2u) tmp[slot + 2u] = tk_memo_id(mv0, mv1, mv2, 2u) + t.num_special;

@@ -43,7 +43,7 @@ def test_device_source_under_asan_ubsan():
         sel = ["tests/test_flat_path.py", "tests/test_kernel_emu.py", "tests/test_oracle_golden.py", "tests/test_merge_golden.py",
                "tests/test_long_merge_emu.py"]
         extra = ["-k", "test_block_merges_on_repetitive or test_emu_cut_decomposition or test_emu_flat_utf8 or test_emu_flat_runs_and_misses or test_emu_flat_dense_pieces or test_emu_flat_baseline_shapes "
-                       "or test_emu_flat_handback_and_mixed or test_emu_flat_small_alphabet_packed or test_emu_flat_every_ascii_byte_pair "
+                       "or test_emu_memo_of_merged_pieces or test_emu_flat_handback_and_mixed or test_emu_flat_small_alphabet_packed or test_emu_flat_every_ascii_byte_pair "
                        "or test_emu_long_single_piece or test_emu_split_only or test_emu_small_vocab_known_answer "
                        "or test_emu_reference_vectors_on_consistent_vocab or test_split_matches_independent_engine "
                        "or test_small_vocab_known_answer or test_reference_vectors_on_consistent_vocab or test_encode_properties "

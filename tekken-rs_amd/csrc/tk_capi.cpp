@@ -610,6 +610,7 @@ static int memo_prepare(tk_ctx* c, TkFlatArgs& fa, hipStream_t s) {
     fa.memo_log_waves = log_waves;
     TK_HIP(c, hipMemsetAsync(fa.memo_log_counts, 0, (size_t)log_waves * 4, s));   // (waves the grid does not launch log nothing)
     fa.memo_epoch = ++c->memo_epoch;
+    fa.memo_probe = c->memo_epoch > 1 ? 1 : 0;            // (the first call on an empty table: nothing to find, only to fill)
     fa.memo_hits = (uint32_t*)c->counters.p + 24;
     c->memo_active_last = true;
     return TK_OK;

@@ -492,7 +492,7 @@ hipError_t tk_launch_flat(const TkFlatArgs& a, hipStream_t s) {
     if (blocks > cap) blocks = cap;
     if (a.pattern == 1) hipLaunchKernelGGL(tk_flat_json_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.dbg_ablate || a.dbg_starts) hipLaunchKernelGGL(tk_flat_split_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
-    else if (a.t.key_hash_mode == 0u && a.memo_tab) hipLaunchKernelGGL(tk_flat_memo_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
+    else if (a.t.key_hash_mode == 0u && a.memo_tab && a.memo_probe) hipLaunchKernelGGL(tk_flat_memo_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else if (a.t.key_hash_mode == 0u) hipLaunchKernelGGL(tk_flat_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(tk_flat_mode1_kernel, dim3((uint32_t)blocks), dim3(TKF_BLOCK), 0, s, a);
     if (a.cut_list && a.pattern == 0) {

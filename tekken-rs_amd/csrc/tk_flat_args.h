@@ -78,6 +78,8 @@ struct TkFlatArgs {
                                  // of 2..16 bytes that is no vocabulary key -- a hit reserves exactly its ids' slots and stores them: no queue
                                  // entry, no holes
     uint32_t memo_mask;          // entries - 1
+    int memo_probe;              // 0: this call only FILLS the table (its first call: an empty table answers nothing, and a look-up is a
+                                 // dependent load in the flat kernel's miss path) -- the flat kernel runs without the look-up
     uint32_t memo_epoch;         // number of this call (> 0, rising): the claim word of tk_memo_commit_one
     uint32_t* memo_hits;         // device counter: memo hits of the call (the host's hit-rate policy); may be NULL
     tk_memo_entry* memo_log;     // what the merge kernel merged into <= TK_MEMO_MAXIDS ids in this call (epoch word = table slot): merge wave w

@@ -444,7 +444,7 @@ TK_DEV void tk_flat_init_lds(const TkFlatArgs& a, uint32_t* lds, int lane) {
     if (lane == 0) {
         // row 0 of the key masks is never read (no piece has length 0): it holds the memo's constants -- table base, mask -- and the
         // wave's count of memo hits (tk_flat_flush_memo_hits); the kernel has no LDS granule and no scalar register to spare
-        const uint64_t mb = (uint64_t)reinterpret_cast<uintptr_t>(a.memo_tab);
+        const uint64_t mb = a.memo_probe ? (uint64_t)reinterpret_cast<uintptr_t>(a.memo_tab) : 0ull;
         lds[TKF_L_MEMO + 0] = (uint32_t)mb; lds[TKF_L_MEMO + 1] = (uint32_t)(mb >> 32);
         lds[TKF_L_MEMO + 2] = a.memo_mask;
         lds[TKF_L_MEMO + 3] = 0u;

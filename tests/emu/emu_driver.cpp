@@ -157,6 +157,7 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         if (reinterpret_cast<uintptr_t>(g_memo) % 32) { g_err = "memo table must be 32-byte aligned"; return TK_ERR_INVALID_ARG; }
         g_memo_hits = 0;
         fa.memo_tab = g_memo; fa.memo_mask = g_memo_mask; fa.memo_epoch = ++g_memo_epoch; fa.memo_hits = &g_memo_hits;
+        fa.memo_probe = g_memo_epoch > 1 ? 1 : 0;
     }
     // the log: three "waves" (the narrow groups are dealt out over them), each with its own stretch
     const uint32_t memo_waves = 3;

@@ -218,7 +218,7 @@ def main():
         data, offs, n_bytes = dk, ok, int(ok[-1])           # (the last batch: what the CPU legs and the bit-exact check look at)
         d_bytes, d_offs = fresh[-1][0], fresh[-1][1]
         torch.cuda.synchronize()
-    eng.set_memo(22 if fresh else 0, 0)
+    eng.set_memo(int(os.environ.get("TK_MEMO_LOG2", "24")) if fresh else 0, 1 if os.environ.get("TK_MEMO_POLICY") == "always" else 0)
     step_no = [0]
     bytes_seen = [0]
 
@@ -532,7 +532,7 @@ def extra_legs(args, tk):
     out["configs[4]_share"] = dict(shape_leg(tk, dflt, "zipf", 500_000, 0, steps=5, seed_off=1), workload="500 k Zipf-length docs 16 B - 32 KiB = one GPU's share of BASELINE configs[4]")
     out["heldout"] = dict(shape_leg(tk, held, "ascii", 1_000_000, 512, steps=10, seed_off=1),
                           workload="configs[1] shape, vocabulary that never saw ~15 % of the word occurrences (--vocab-fit heldout)")
-    out["heldout_memo"] = dict(shape_leg(tk, held, "ascii", 1_000_000, 512, steps=0, fresh=8, memo_log2=22, seed_off=1),
+    out["heldout_memo"] = dict(shape_leg(tk, held, "ascii", 1_000_000, 512, steps=0, fresh=8, memo_log2=int(os.environ.get("TK_MEMO_LOG2", "24")), seed_off=1),
                                workload="the same shape and vocabulary, memo of merged pieces on, measured on FRESH batches only")
     return out
 

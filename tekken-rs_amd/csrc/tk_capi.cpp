@@ -167,7 +167,7 @@ struct tk_ctx {
     bool small_ready = false;      // small_prepare() went through completely
     // memo of merged pieces (tk_hash.h MEMO; include/tekken_hip.h tk_ctx_set_memo)
     DevBuf t_memo, t_memo_log;
-    uint32_t memo_log2 = 22;       // entries = 2^memo_log2 (32 bytes each), 0 = off; TK_MEMO_LOG2
+    uint32_t memo_log2 = 24;       // entries = 2^memo_log2 (32 bytes each: 512 MB of a 288 GB part), 0 = off; TK_MEMO_LOG2
     uint32_t memo_have_log2 = 0;   // size of the table that is allocated (0: none yet)
     uint32_t memo_epoch = 0;       // calls that used the table so far
     int memo_policy = 0;           // 0 adaptive (pause while the hit rate is low), 1 always on; TK_MEMO_POLICY=always
@@ -594,7 +594,11 @@ static int memo_prepare(tk_ctx* c, TkFlatArgs& fa, hipStream_t s) {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     const uint32_t log_waves = (uint32_t)cus * 16u;
-    const uint32_t log_cap = 1u << (c->memo_log2 > 23 ? 21 : c->memo_log2 - 2);
+    // (TK_MEMO_LOG_LOG2: records of the log, all waves together; measured on the held-out shape: what bounds the hit rate of a table
+    // of 2^22 entries is how many new entries a call can log, not the table)
+    uint32_t log_log2 = c->memo_log2 > 23 ? 21 : c->memo_log2 - 2;
+    if (const char* ll = getenv("TK_MEMO_LOG_LOG2")) { const int v = atoi(ll); if (v >= 8 && v <= 24) log_log2 = (uint32_t)v; }
+    const uint32_t log_cap = 1u << log_log2;
     const uint32_t per_wave = log_cap / log_waves > 0 ? log_cap / log_waves : 1u;
     if (c->t_memo_log.reserve((size_t)per_wave * log_waves * sizeof(tk_memo_entry) + (size_t)log_waves * 4) != hipSuccess) {
         (void)hipGetLastError();

@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--vocab-fit", default="same"); ap.add_argument("--kind", default="ascii"); ap.add_argument("--doc-len", type=int, default=512)
 ap.add_argument("--docs", type=int, default=1000000); ap.add_argument("--batches", type=int, default=4); ap.add_argument("--repeat", action="store_true")
 ap.add_argument("--ablate", default="", help="development build only: comma list of TK_DEBUG_ABLATE values, applied one per extra pass over the LAST batch")
-ap.add_argument("--log2", type=int, default=22); ap.add_argument("--policy", type=int, default=1)
+ap.add_argument("--log2", type=int, default=24); ap.add_argument("--policy", type=int, default=1)
 a = ap.parse_args()
 vp = sv.ensure_heldout() if a.vocab_fit == "heldout" else sv.ensure_default()
 tokz = tk.Tekkenizer.from_file(vp, device=0); eng = tokz.engine()

@@ -107,7 +107,7 @@ uint64_t tk_cut_chunks(const tk_ctx* ctx);
 uint64_t tk_last_host_syncs(const tk_ctx* ctx);
 
 /* Memo of merged pieces (no reference equivalent; `encode` is a pure function of the text, src/tekkenizer.rs:384-386, and stays
- * one): a device table {piece of 2..16 bytes that is no vocabulary key -> the <= 4 ids the byte-pair merge gives it}, read by the
+ * one): a device table {piece of 2..16 bytes that is no vocabulary key -> the <= 5 ids the byte-pair merge gives it}, read by the
  * split + look-up kernel, filled behind the merge kernel, visible from the NEXT call on the context.  Text repeats its unknown
  * words; a hit costs one 32-byte gather instead of a chain of ~20 dependent PAIR probes.  An entry holds the exact key and the
  * exact result: the table can change how long a call takes, never an id (tests/test_gpu_parity.py::test_memo_*).

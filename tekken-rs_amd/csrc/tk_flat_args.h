@@ -80,9 +80,9 @@ struct TkFlatArgs {
     uint32_t memo_mask;          // entries - 1
     int memo_probe;              // 0: this call only FILLS the table (its first call: an empty table answers nothing, and a look-up is a
                                  // dependent load in the flat kernel's miss path) -- the flat kernel runs without the look-up
-    uint32_t memo_epoch;         // number of this call (> 0, rising): the claim word of tk_memo_commit_one
+    uint32_t memo_epoch;         // number of this call on the context (> 0, rising)
     uint32_t* memo_hits;         // device counter: memo hits of the call (the host's hit-rate policy); may be NULL
-    tk_memo_entry* memo_log;     // what the merge kernel merged into <= TK_MEMO_MAXIDS ids in this call (epoch word = table slot): merge wave w
+    tk_memo_entry* memo_log;     // what the merge kernel merged into <= TK_MEMO_MAXIDS ids in this call (every record is the entry it will become): merge wave w
                                  // owns records [w * memo_log_per_wave, (w + 1) * memo_log_per_wave) and leaves their number in
                                  // memo_log_counts[w]; tk_memo_claim_kernel / tk_memo_commit_kernel move them into the table
     uint32_t* memo_log_counts;   // [memo_log_waves]

@@ -1089,7 +1089,8 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         const uint64_t MB = wv_ballot(miss);
         uint32_t res = len;                                 // id slots of a missed piece
         bool mhit = false;
-        uint32_t mv0 = 0, mv1 = 0, mv2 = 0;
+        uint32_t mv0 = 0, mv1 = 0, mv2 = 0, mv4 = 0;        // the entry's rank words; mv4 = its fifth rank (kept across the slot scan: loading
+                                                            // the entry again where the ids are stored was a second dependent load, +0.08 ms)
         if (MB) {
             // MEMO (tk_hash.h): a piece of 2..16 bytes that is no vocabulary key may have been merged in an earlier call -- its exact
             // key and the ids the merge gave it sit in a 32-byte entry (two loads, one round trip).  A hit reserves exactly its ids'
@@ -1105,7 +1106,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                     if ((((ek.x ^ kk[0]) | (ek.y ^ kk[1]) | (ek.z ^ kk[2]) | (ek.w ^ kk[3])) == 0u) && tk_memo_len(ev.w) == len) {
                         mhit = true;
                         res = tk_memo_n(ev.w);
-                        mv0 = ev.y; mv1 = ev.z; mv2 = ev.w;
+                        mv0 = ev.y; mv1 = ev.z; mv2 = ev.w; mv4 = ev.x;
                     }
                 }
                 const uint64_t HB = wv_ballot(mhit);
@@ -1154,10 +1155,11 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             if (!miss && !TKF_ABL(a, 4)) tmp[slot] = r + t.num_special;
         }
         if (MEMO && mhit) {                                 // the ids of the memo entry
-            tmp[slot] = tk_memo_id(mv0, mv1, mv2, 0u) + t.num_special;
-            if (res > 1u) tmp[slot + 1u] = tk_memo_id(mv0, mv1, mv2, 1u) + t.num_special;
-            if (res > 2u) tmp[slot + 2u] = tk_memo_id(mv0, mv1, mv2, 2u) + t.num_special;
-            if (res > 3u) tmp[slot + 3u] = tk_memo_id(mv0, mv1, mv2, 3u) + t.num_special;
+            tmp[slot] = tk_memo_id(mv4, mv0, mv1, mv2, 0u) + t.num_special;
+            if (res > 1u) tmp[slot + 1u] = tk_memo_id(mv4, mv0, mv1, mv2, 1u) + t.num_special;
+            if (res > 2u) tmp[slot + 2u] = tk_memo_id(mv4, mv0, mv1, mv2, 2u) + t.num_special;
+            if (res > 3u) tmp[slot + 3u] = tk_memo_id(mv4, mv0, mv1, mv2, 3u) + t.num_special;
+            if (res > 4u) tmp[slot + 4u] = tk_memo_id(mv4, mv0, mv1, mv2, 4u) + t.num_special;
         }
     }
     if (pass + 1 < npass) {
@@ -1535,18 +1537,18 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                     const int keep = (int)len - 4 * q;
                     k[q] = (q < N / 4 && keep > 0) ? (kk[q < N / 4 ? q : 0] & (keep >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u))) : 0u;
                 }
-                uint32_t r4[4] = {0u, 0u, 0u, 0u};
+                uint32_t r5[5] = {0u, 0u, 0u, 0u, 0u};
                 alive_t rem = alive;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((uint32_t)q < np) r4[q] = tokc[tkm_ctz(rem) * 64u];
+                for (int q = 0; q < 5; ++q) {
+                    if ((uint32_t)q < np) r5[q] = tokc[tkm_ctz(rem) * 64u];
                     rem = tkm_clear_lowest(rem);
                 }
-                uint32_t v[3];
-                tk_memo_pack(r4, np, len, v);
-                tk_memo_entry* w = ml->base + at;           // (a log record is an entry whose epoch word holds the table slot)
+                uint32_t v[3], w4;
+                tk_memo_pack(r5, np, len, &w4, v);
+                tk_memo_entry* w = ml->base + at;           // (a log record is the entry it will become)
                 wv_store16(w->k, k[0], k[1], k[2], k[3]);
-                wv_store16(&w->epoch, tk_memo_slot(tk_key_hash(t.key_hash_mode, k[0], k[1], k[2], k[3], len)) & a.memo_mask, v[0], v[1], v[2]);
+                wv_store16(&w->w4, w4, v[0], v[1], v[2]);
             }
             const uint32_t nn = ml->n + (uint32_t)tk_popc64(IB);
             ml->n = nn < ml->cap ? nn : ml->cap;
@@ -1750,17 +1752,22 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
 // The log of a call's new entries (tk_merge_lds) into the table, in two passes without a single atomic -- a word that is new in this
 // call is new in hundreds of records, and that many read-modify-writes on one address serialise (measured: up to 1.4 ms for a
 // million records).  Record i = j-th record of merge wave w, i = w * per_wave + j, j < counts[w].  Pass 1: every record stores ITS
-// INDEX into the epoch word of its slot (plain stores: one of them stays).  Pass 2, a kernel later: the record whose index is the
+// INDEX into the claim word (w4) of its slot (plain stores: one of them stays).  Pass 2, a kernel later: the record whose index is the
 // one that stayed owns the slot and writes key and ids.  One writer per slot and call by construction; nothing reads the table
 // while the two kernels run.
 TK_DEV bool tk_memo_log_live(const uint32_t* counts, uint32_t per_wave, uint32_t i) { return i % per_wave < counts[i / per_wave]; }
-TK_DEV void tk_memo_claim_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i) { tab[log[i].epoch].epoch = i; }
-TK_DEV void tk_memo_commit_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i) {
+TK_DEV uint32_t tk_memo_slot_of(const tk_memo_entry& r, uint32_t key_hash_mode, uint32_t mask) {
+    return tk_memo_slot(tk_key_hash(key_hash_mode, r.k[0], r.k[1], r.k[2], r.k[3], tk_memo_len(r.v[2]))) & mask;
+}
+TK_DEV void tk_memo_claim_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i, uint32_t key_hash_mode, uint32_t mask) {
+    tab[tk_memo_slot_of(log[i], key_hash_mode, mask)].w4 = i;             // (i < 2^31: never looks like a committed entry's word)
+}
+TK_DEV void tk_memo_commit_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i, uint32_t key_hash_mode, uint32_t mask) {
     const tk_memo_entry r = log[i];
-    tk_memo_entry* w = tab + r.epoch;
-    if (w->epoch == i) {
+    tk_memo_entry* w = tab + tk_memo_slot_of(r, key_hash_mode, mask);
+    if (w->w4 == i) {
         wv_store16(w->k, r.k[0], r.k[1], r.k[2], r.k[3]);
-        w->v[0] = r.v[0]; w->v[1] = r.v[1]; w->v[2] = r.v[2];
+        wv_store16(&w->w4, r.w4, r.v[0], r.v[1], r.v[2]);
     }
 }
 

@@ -123,33 +123,37 @@ TK_HD void tk_k64_step(uint32_t& ha, uint32_t w) { ha = tk_rotl32(ha, 5) ^ w; }
 TK_HD uint32_t tk_k64_slot(uint32_t ha, uint32_t len) { return tk_fmix32(ha + len * 0x165667B1u); }
 TK_HD uint32_t tk_k64_tag(uint32_t ha) { return tk_fmix32(ha ^ 0x85EBCA77u); }   /* other bits of the same hash: the blob compare decides */
 
-/* MEMO: merged pieces of 2..16 bytes that are no vocabulary key -> the ids the byte-pair merge gives them (at most TK_MEMO_MAXIDS).
-   A pure function of the bytes (reference src/tekkenizer.rs:384-386: encode is a function of the text), so an entry can change
-   how long a call takes, never an id.  Direct-mapped, slot tk_memo_slot(tk_key_hash(key, len)) & mask, 32-byte entries:
+/* MEMO: merged pieces of 2..16 bytes that are no vocabulary key -> the ids the byte-pair merge gives them (at most TK_MEMO_MAXIDS = 5:
+   97 % of the missed pieces of running text; four would be 90 %).  A pure function of the bytes (reference src/tekkenizer.rs:384-386:
+   encode is a function of the text), so an entry can change how long a call takes, never an id.  Direct-mapped, slot
+   tk_memo_slot(tk_key_hash(key, len)) & mask, 32-byte entries:
      k[4]   the piece's bytes, zero padded (exact key)
-     epoch  the claim word of tk_memo_claim_one / tk_memo_commit_one (index of the log record that wrote the entry: ONE writer per
-            slot and call)
+     w4     TK_MEMO_TAG | rank4.  Between the two commit kernels of a call this word is the CLAIM word (the index of a log record:
+            tk_memo_claim_one / tk_memo_commit_one, ONE writer per slot and call); a record index never has the tag bit
      v[3]   rank0 | rank1 << 21 | rank2 << 42 (v[0], v[1]);  v[2] = rank3 | len << 21 | n << 26   (ranks, not final ids)
-   An empty entry is all zero: its length 0 matches no piece.  Readers (the flat kernels) and the writer (tk_memo_commit_kernel)
-   never run at the same time: the commit kernel follows a call's flat and merge kernels on the stream, the next call's flat kernel
-   follows it, and a slot has at most one writer per call -- no reader ever sees a torn entry. */
-#define TK_MEMO_MAXIDS 4u
+   An empty entry is all zero: its length 0 matches no piece.  Readers (the flat kernels) and the writers (the two commit kernels)
+   never run at the same time: the commit kernels follow a call's flat and merge kernels on the stream, the next call's flat kernel
+   follows them, and a slot has at most one writer per call -- no reader ever sees a torn entry.  A log record (tk_merge_lds) IS the
+   entry it will become; the commit kernels find its slot from its key. */
+#define TK_MEMO_MAXIDS 5u
+#define TK_MEMO_TAG 0x80000000u
 struct alignas(32) tk_memo_entry {
     uint32_t k[4];
-    uint32_t epoch;
+    uint32_t w4;
     uint32_t v[3];
 };
 TK_HD uint32_t tk_memo_slot(uint32_t h) { return tk_rotl32(h, 11) ^ (h >> 3); }
 TK_HD uint32_t tk_memo_len(uint32_t v2) { return (v2 >> 21) & 31u; }
 TK_HD uint32_t tk_memo_n(uint32_t v2) { return (v2 >> 26) & 7u; }
-TK_HD uint32_t tk_memo_id(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {      /* i = 0..3 */
+TK_HD uint32_t tk_memo_id(uint32_t w4, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t i) {      /* i = 0..4 */
     const uint32_t m = (1u << TK_ID_BITS) - 1u;
-    return i == 0u ? (v0 & m) : i == 1u ? (((v0 >> 21) | (v1 << 11)) & m) : i == 2u ? ((v1 >> 10) & m) : (v2 & m);
+    return i == 0u ? (v0 & m) : i == 1u ? (((v0 >> 21) | (v1 << 11)) & m) : i == 2u ? ((v1 >> 10) & m) : i == 3u ? (v2 & m) : (w4 & m);
 }
-TK_HD void tk_memo_pack(const uint32_t* r, uint32_t n, uint32_t len, uint32_t* v) {  /* r[0..n): ranks < 2^21, unused ones 0 */
+TK_HD void tk_memo_pack(const uint32_t* r, uint32_t n, uint32_t len, uint32_t* w4, uint32_t* v) {  /* r[0..5): ranks < 2^21, unused ones 0 */
     const uint64_t lo = (uint64_t)r[0] | ((uint64_t)r[1] << 21) | ((uint64_t)r[2] << 42);
     v[0] = (uint32_t)lo; v[1] = (uint32_t)(lo >> 32);
     v[2] = r[3] | (len << 21) | (n << 26);
+    *w4 = TK_MEMO_TAG | r[4];
 }
 
 /* cut rule (tk_tables.cpp make_cut_tables): exact bit maps over byte bigrams / trigrams */

@@ -235,13 +235,20 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
             return true;
         };
         for (uint64_t w = 0; w * 64 < n_narrow; ++w) {
-            TkMemoLog ml;
+            // (on the device the log position is a register of every lane, wave-uniform: one copy per emulated lane)
+            TkMemoLog mls[64];
             const uint32_t mw = (uint32_t)(w % memo_waves);
-            ml.base = fa.memo_log ? fa.memo_log + (size_t)mw * fa.memo_log_per_wave : nullptr;
-            ml.n = fa.memo_log ? memo_log_counts[mw] : 0u;
-            ml.cap = fa.memo_log ? fa.memo_log_per_wave : 0u;
-            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data() + G, fa.t.pair_filter, fa.memo_log ? &ml : nullptr); });
-            if (fa.memo_log) memo_log_counts[mw] = ml.n;
+            for (int l = 0; l < 64; ++l) {
+                mls[l].base = fa.memo_log ? fa.memo_log + (size_t)mw * fa.memo_log_per_wave : nullptr;
+                mls[l].n = fa.memo_log ? memo_log_counts[mw] : 0u;
+                mls[l].cap = fa.memo_log ? fa.memo_log_per_wave : 0u;
+            }
+            tkemu::run_wave([&](int lane) { tk_merge_wave<false>(fa, w, lane, mlds.data() + G, fa.t.pair_filter, fa.memo_log ? &mls[lane] : nullptr); });
+            if (fa.memo_log) {
+                for (int l = 1; l < 64; ++l)
+                    if (mls[l].n != mls[0].n) { g_err = "memo log position is not wave-uniform"; return TK_ERR_RUNTIME; }
+                memo_log_counts[mw] = mls[0].n;
+            }
             if (!guards_ok(TKM_LDS_WORDS(16))) { g_err = "tk_merge_wave<false> wrote outside its LDS columns"; return TK_ERR_RUNTIME; }
             ops += tkemu::g_wave->n_ops;
         }
@@ -265,11 +272,11 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         const uint32_t nl = fa.memo_log_per_wave * fa.memo_log_waves;
         for (uint32_t i = 0; i < nl; ++i) {
             if (!tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) continue;
-            if (memo_log[i].epoch > fa.memo_mask) { g_err = "memo log: slot out of range"; return TK_ERR_RUNTIME; }
-            tk_memo_claim_one(fa.memo_tab, memo_log.data(), i);
+            if (!(memo_log[i].w4 & TK_MEMO_TAG) || tk_memo_n(memo_log[i].v[2]) == 0u || tk_memo_n(memo_log[i].v[2]) > TK_MEMO_MAXIDS) { g_err = "memo log: malformed record " + std::to_string(i) + " w4=" + std::to_string(memo_log[i].w4) + " v2=" + std::to_string(memo_log[i].v[2]) + " counts=" + std::to_string(memo_log_counts[i / fa.memo_log_per_wave]); return TK_ERR_RUNTIME; }
+            tk_memo_claim_one(fa.memo_tab, memo_log.data(), i, fa.t.key_hash_mode, fa.memo_mask);
         }
         for (uint32_t i = 0; i < nl; ++i)
-            if (tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) tk_memo_commit_one(fa.memo_tab, memo_log.data(), i);
+            if (tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) tk_memo_commit_one(fa.memo_tab, memo_log.data(), i, fa.t.key_hash_mode, fa.memo_mask);
     }
     // the long-piece records (tk_flat_long_kernel): one wave each; a piece beyond TKF_LONGCAP flags its document; those of up
     // to 128 bytes that are no vocabulary keys go on to the lane-per-piece merge (tk_flat_long128_kernel)

@@ -111,6 +111,16 @@ extern "C" void emu_memo_info(uint64_t* out) {
     if (g_memo) for (uint32_t i = 0; i <= g_memo_mask; ++i) out[2] += tk_memo_len(g_memo[i].v[2]) != 0u;
 }
 
+// the memo entry's packing (tk_hash.h): ranks in, ranks out; returns 0 if every field comes back
+extern "C" int emu_memo_pack_roundtrip(const uint32_t* ranks5, uint32_t n, uint32_t len) {
+    uint32_t w4 = 0, v[3] = {0, 0, 0};
+    tk_memo_pack(ranks5, n, len, &w4, v);
+    if (!(w4 & TK_MEMO_TAG) || tk_memo_n(v[2]) != n || tk_memo_len(v[2]) != len) return 1;
+    for (uint32_t i = 0; i < 5; ++i)
+        if (tk_memo_id(w4, v[0], v[1], v[2], i) != ranks5[i]) return 2 + (int)i;
+    return 0;
+}
+
 // Flat path on the emulator: tk_flat_chunk for every chunk (one emulated wave), the flagged documents through
 // the per-document algorithm (mode 3, then pass 2), and host restatements of the small bookkeeping kernels of
 // tk_flat.hip (first_doc, todo list, chunk prefix sums, counts, assemble).

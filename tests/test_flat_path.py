@@ -463,3 +463,21 @@ def test_emu_memo_of_merged_pieces(test_vocab, small_vocab):
         assert emu.memo_info()["hits_last"] > 0
     finally:
         emu.memo_set(0)
+
+
+def test_memo_entry_packing_round_trip():
+    """tk_memo_pack / tk_memo_id / tk_memo_n / tk_memo_len (csrc/tk_hash.h): five 21-bit ranks, the length and the count survive the 32-byte
+    entry's packing for every count and at the extremes of every field; the fifth rank shares its word with the tag bit that tells
+    a committed entry from a claim (a log-record index)."""
+    import ctypes
+    import numpy as np
+    L = emu.lib()
+    L.emu_memo_pack_roundtrip.restype = ctypes.c_int
+    L.emu_memo_pack_roundtrip.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    rng = random.Random(3)
+    top = (1 << 21) - 1
+    for _ in range(4000):
+        n = rng.randint(1, 5)
+        r = [rng.choice([0, 1, top, top - 1, rng.randint(0, top)]) for _ in range(n)] + [0] * (5 - n)
+        a = np.array(r, np.uint32)
+        assert L.emu_memo_pack_roundtrip(a.ctypes.data, n, rng.randint(2, 16)) == 0, (r, n)

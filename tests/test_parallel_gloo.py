@@ -128,3 +128,22 @@ def test_shard_by_bytes_balances_bytes():
         per = [int(offs[cuts[r + 1]]) - int(offs[cuts[r]]) for r in range(world)]
         assert max(per) - min(per) <= 2 * 30000 + 200
     assert par.shard_by_bytes(np.zeros(1, np.uint64), 4) == [0, 0, 0, 0, 0]
+
+
+def test_bench_link_model_arithmetic():
+    """bench.py's link_model object (N > 1 lines): the bytes a peer sends (ids at the wire width + u32 counts), the link time at the assumed
+    one-way rate and the step DESIGN.md section 5 expects from them -- max(kernels, link) with the gather beside the kernels, their sum
+    without."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lm = bench.link_model(8, [[1.3, 5.12e8]] * 8, 8 * 98_000_000, 8_000_000, 18, 6.5)
+    assert lm["peers"] == 7 and lm["bytes_per_peer"] == int(98_000_000 * 18 / 8 + 1_000_000 * 4)
+    assert abs(lm["expected_link_ms"] - lm["bytes_per_peer"] / 64e9 * 1e3) < 1e-3
+    assert lm["expected_step_ms_overlap"] == max(lm["kernels_ms_max"], lm["expected_link_ms"])
+    assert abs(lm["expected_step_ms_sync"] - (lm["kernels_ms_max"] + lm["expected_link_ms"])) < 2e-3
+    one = bench.link_model(1, [[1.3, 5.12e8]], 98_000_000, 1_000_000, 32, 1.3)
+    assert one["peers"] == 0 and one["expected_link_ms"] == 0.0

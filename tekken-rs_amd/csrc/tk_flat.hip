@@ -191,14 +191,7 @@ __global__ __launch_bounds__(TKM_BLOCK) void tk_merge_kernel(TkFlatArgs a) {   /
     if (a.memo_log && wave < a.memo_log_waves && wv_lane() == 0) a.memo_log_counts[wave] = ml.n;
 }
 
-// the log of the merge kernel's new memo entries into the table: claim, then commit (tk_memo_claim_one / tk_memo_commit_one)
-__global__ __launch_bounds__(TKF_BLOCK) void tk_memo_claim_kernel(tk_memo_entry* __restrict__ tab, const tk_memo_entry* __restrict__ log,
-                                                                   const uint32_t* __restrict__ counts, uint32_t per_wave, uint32_t n_waves,
-                                                                   uint32_t key_hash_mode, uint32_t mask) {
-    const uint32_t n = per_wave * n_waves;
-    for (uint32_t i = blockIdx.x * TKF_BLOCK + threadIdx.x; i < n; i += gridDim.x * TKF_BLOCK)
-        if (tk_memo_log_live(counts, per_wave, i)) tk_memo_claim_one(tab, log, i, key_hash_mode, mask);
-}
+// the log of the merge kernel's new memo entries into the table (tk_memo_commit_one; the slots were claimed where the records were written)
 __global__ __launch_bounds__(TKF_BLOCK) void tk_memo_commit_kernel(tk_memo_entry* __restrict__ tab, const tk_memo_entry* __restrict__ log,
                                                                     const uint32_t* __restrict__ counts, uint32_t per_wave, uint32_t n_waves,
                                                                     uint32_t key_hash_mode, uint32_t mask) {
@@ -542,7 +535,6 @@ hipError_t tk_launch_merge(const TkFlatArgs& a, uint32_t* narrow_left_out, hipSt
     hipLaunchKernelGGL(tk_merge_kernel, dim3((uint32_t)b1), dim3(TKM_BLOCK), TKM_LDS_BYTES, s, a);
     hipLaunchKernelGGL(tk_merge_wide_kernel, dim3((uint32_t)b2), dim3(TKM_WIDE_BLOCK), TKM_WIDE_LDS_BYTES, s, a);
     if (a.memo_tab && a.memo_log) {
-        hipLaunchKernelGGL(tk_memo_claim_kernel, dim3(1024), dim3(TKF_BLOCK), 0, s, a.memo_tab, a.memo_log, a.memo_log_counts, a.memo_log_per_wave, a.memo_log_waves, a.t.key_hash_mode, a.memo_mask);
         hipLaunchKernelGGL(tk_memo_commit_kernel, dim3(1024), dim3(TKF_BLOCK), 0, s, a.memo_tab, a.memo_log, a.memo_log_counts, a.memo_log_per_wave, a.memo_log_waves, a.t.key_hash_mode, a.memo_mask);
     }
     return hipGetLastError();

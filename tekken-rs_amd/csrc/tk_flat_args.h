@@ -84,7 +84,7 @@ struct TkFlatArgs {
     uint32_t* memo_hits;         // device counter: memo hits of the call (the host's hit-rate policy); may be NULL
     tk_memo_entry* memo_log;     // what the merge kernel merged into <= TK_MEMO_MAXIDS ids in this call (every record is the entry it will become): merge wave w
                                  // owns records [w * memo_log_per_wave, (w + 1) * memo_log_per_wave) and leaves their number in
-                                 // memo_log_counts[w]; tk_memo_claim_kernel / tk_memo_commit_kernel move them into the table
+                                 // memo_log_counts[w]; tk_memo_commit_kernel moves them into the table
     uint32_t* memo_log_counts;   // [memo_log_waves]
     uint32_t memo_log_per_wave, memo_log_waves;
     uint8_t* dbg_starts;         // optional: per-byte piece-start flags

@@ -1523,9 +1523,9 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
     if (!C && ml != nullptr) {
         // MEMO (tk_hash.h): what this piece merged into, for the look-ups of the NEXT call -- exact key (the bytes, zero padded,
         // and the length), at most TK_MEMO_MAXIDS ranks.  The entry goes into this wave's stretch of a LOG (a full stretch drops
-        // it, which only delays the entry by a call); tk_memo_claim_kernel / tk_memo_commit_kernel put the log into the table
-        // behind the merge kernels -- a hot new word arrives in hundreds of lanes at once, and claiming table slots from here
-        // would serialise them.
+        // it, which only delays the entry by a call); tk_memo_commit_kernel puts the log into the table behind the merge kernels
+        // -- a hot new word arrives in hundreds of lanes at once, and taking table slots with atomics from here would serialise
+        // them.
         const bool ins = mine && np <= TK_MEMO_MAXIDS;
         const uint64_t IB = wv_ballot(ins);
         if (IB && ml->n < ml->cap) {
@@ -1549,6 +1549,10 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                 tk_memo_entry* w = ml->base + at;           // (a log record is the entry it will become)
                 wv_store16(w->k, k[0], k[1], k[2], k[3]);
                 wv_store16(&w->w4, w4, v[0], v[1], v[2]);
+                // ... and CLAIMS its slot: the record's index into the slot's claim word, a plain store -- of all the records that want
+                // a slot in this call one index stays, and tk_memo_commit_kernel lets that record write (nothing reads the table
+                // while the merge and commit kernels run)
+                a.memo_tab[tk_memo_slot(tk_key_hash(t.key_hash_mode, k[0], k[1], k[2], k[3], len)) & a.memo_mask].w4 = (uint32_t)(w - a.memo_log);
             }
             const uint32_t nn = ml->n + (uint32_t)tk_popc64(IB);
             ml->n = nn < ml->cap ? nn : ml->cap;
@@ -1749,18 +1753,15 @@ TK_DEV void tk_merge_items(const TkFlatArgs& a, bool have, uint32_t rec, uint32_
     tk_merge_holes(a, have, holes, chunk, g, lane);
 }
 
-// The log of a call's new entries (tk_merge_lds) into the table, in two passes without a single atomic -- a word that is new in this
-// call is new in hundreds of records, and that many read-modify-writes on one address serialise (measured: up to 1.4 ms for a
-// million records).  Record i = j-th record of merge wave w, i = w * per_wave + j, j < counts[w].  Pass 1: every record stores ITS
-// INDEX into the claim word (w4) of its slot (plain stores: one of them stays).  Pass 2, a kernel later: the record whose index is the
-// one that stayed owns the slot and writes key and ids.  One writer per slot and call by construction; nothing reads the table
-// while the two kernels run.
+// The log of a call's new entries (tk_merge_lds) into the table, without a single atomic -- a word that is new in this call is new in
+// hundreds of records, and that many read-modify-writes on one address serialise (measured: up to 1.4 ms for a million records).
+// Record i = j-th record of merge wave w, i = w * per_wave + j, j < counts[w].  Step 1, in the merge kernel where the record is
+// written: its INDEX goes into the claim word (w4) of its slot (plain stores: one of them stays).  Step 2, tk_memo_commit_kernel behind
+// the merge kernels: the record whose index is the one that stayed owns the slot and writes key and ids.  One writer per slot and call
+// by construction; nothing reads the table while the merge and commit kernels run.
 TK_DEV bool tk_memo_log_live(const uint32_t* counts, uint32_t per_wave, uint32_t i) { return i % per_wave < counts[i / per_wave]; }
 TK_DEV uint32_t tk_memo_slot_of(const tk_memo_entry& r, uint32_t key_hash_mode, uint32_t mask) {
     return tk_memo_slot(tk_key_hash(key_hash_mode, r.k[0], r.k[1], r.k[2], r.k[3], tk_memo_len(r.v[2]))) & mask;
-}
-TK_DEV void tk_memo_claim_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i, uint32_t key_hash_mode, uint32_t mask) {
-    tab[tk_memo_slot_of(log[i], key_hash_mode, mask)].w4 = i;             // (i < 2^31: never looks like a committed entry's word)
 }
 TK_DEV void tk_memo_commit_one(tk_memo_entry* tab, const tk_memo_entry* log, uint32_t i, uint32_t key_hash_mode, uint32_t mask) {
     const tk_memo_entry r = log[i];

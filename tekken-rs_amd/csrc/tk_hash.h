@@ -129,10 +129,10 @@ TK_HD uint32_t tk_k64_tag(uint32_t ha) { return tk_fmix32(ha ^ 0x85EBCA77u); }  
    tk_memo_slot(tk_key_hash(key, len)) & mask, 32-byte entries:
      k[4]   the piece's bytes, zero padded (exact key)
      w4     TK_MEMO_TAG | rank4.  Between the two commit kernels of a call this word is the CLAIM word (the index of a log record:
-            tk_memo_claim_one / tk_memo_commit_one, ONE writer per slot and call); a record index never has the tag bit
+            tk_merge_lds / tk_memo_commit_one, ONE writer per slot and call); a record index never has the tag bit
      v[3]   rank0 | rank1 << 21 | rank2 << 42 (v[0], v[1]);  v[2] = rank3 | len << 21 | n << 26   (ranks, not final ids)
-   An empty entry is all zero: its length 0 matches no piece.  Readers (the flat kernels) and the writers (the two commit kernels)
-   never run at the same time: the commit kernels follow a call's flat and merge kernels on the stream, the next call's flat kernel
+   An empty entry is all zero: its length 0 matches no piece.  Readers (the flat kernels) and the writers (the merge kernel's claim stores and the commit kernel)
+   never run at the same time: merge and commit kernels follow a call's flat and merge kernels on the stream, the next call's flat kernel
    follows them, and a slot has at most one writer per call -- no reader ever sees a torn entry.  A log record (tk_merge_lds) IS the
    entry it will become; the commit kernels find its slot from its key. */
 #define TK_MEMO_MAXIDS 5u

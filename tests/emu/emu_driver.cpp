@@ -283,7 +283,6 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
         for (uint32_t i = 0; i < nl; ++i) {
             if (!tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) continue;
             if (!(memo_log[i].w4 & TK_MEMO_TAG) || tk_memo_n(memo_log[i].v[2]) == 0u || tk_memo_n(memo_log[i].v[2]) > TK_MEMO_MAXIDS) { g_err = "memo log: malformed record " + std::to_string(i) + " w4=" + std::to_string(memo_log[i].w4) + " v2=" + std::to_string(memo_log[i].v[2]) + " counts=" + std::to_string(memo_log_counts[i / fa.memo_log_per_wave]); return TK_ERR_RUNTIME; }
-            tk_memo_claim_one(fa.memo_tab, memo_log.data(), i, fa.t.key_hash_mode, fa.memo_mask);
         }
         for (uint32_t i = 0; i < nl; ++i)
             if (tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) tk_memo_commit_one(fa.memo_tab, memo_log.data(), i, fa.t.key_hash_mode, fa.memo_mask);

@@ -433,6 +433,7 @@ def main():
             out["link_model"] = link_model(world, per_rank, total_ids, total_docs, 18 if codec else 32, ms_per_step)
         if not distributed and args.extra_legs == "auto" and args.kind == "ascii" and not args.vocab and args.vocab_fit == "same" \
                 and n_docs == 1_000_000 and args.doc_len == 512 and not fresh:
+            out["two_in_flight"] = in_flight_leg(tk, vocab_path, eng, d_bytes, d_offs, n_docs, n_bytes, ms_per_step)
             tokz.close()
             tokz = None
             del d_bytes, d_offs
@@ -520,6 +521,42 @@ def shape_leg(tk, vocab_path, kind, n_docs, doc_len, steps, warmup=1, fresh=0, m
     else:
         out["protocol"] = "one batch repeated, memo OFF"
     return out
+
+
+def in_flight_leg(tk, vocab_path, eng, d_bytes, d_offs, n_docs, n_bytes, serial_ms, calls=100):
+    """What a host that keeps TWO batches in flight gets out of one GPU: a second context (contexts are independent: own tables, scratch,
+    streams), two host threads, each `calls` whole calls on the same resident batch (memo off).  The small kernels and the two host
+    waits of one call run beside the big kernels of the other.  Not `value`: that stays one call at a time."""
+    import threading
+    import torch
+    tok2 = tk.Tekkenizer.from_file(vocab_path, device=0)
+    engs = [eng, tok2.engine()]
+    engs[1].set_memo(0, 0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    views = [None, None]
+
+    def worker(i, k):
+        for _ in range(k):
+            views[i] = engs[i].encode_batch_device_views(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, True, True, streams[i].cuda_stream)
+
+    def timed(k):
+        ths = [threading.Thread(target=worker, args=(i, k)) for i in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / (2 * k)
+
+    timed(3)
+    ms = timed(calls)
+    same = all(bool(torch.equal(torch.as_tensor(views[0][j], device="cuda"), torch.as_tensor(views[1][j], device="cuda"))) for j in (0, 1))
+    tok2.close()
+    return {"ms_per_batch": round(ms, 4), "MBps": round(n_bytes / 1e6 / (ms * 1e-3), 1), "calls_timed": 2 * calls, "one_at_a_time_ms": round(serial_ms, 4),
+            "speedup": round(serial_ms / ms, 3), "both_contexts_same_ids": same,
+            "protocol": "two contexts, two host threads, the same resident batch, memo OFF; wall clock over all calls / calls"}
 
 
 def extra_legs(args, tk):

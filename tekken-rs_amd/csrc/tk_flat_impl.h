@@ -1526,17 +1526,33 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
         // it, which only delays the entry by a call); tk_memo_commit_kernel puts the log into the table behind the merge kernels
         // -- a hot new word arrives in hundreds of lanes at once, and taking table slots with atomics from here would serialise
         // them.
-        const bool ins = mine && np <= TK_MEMO_MAXIDS;
-        const uint64_t IB = wv_ballot(ins);
-        if (IB && ml->n < ml->cap) {
-            const uint32_t at = ml->n + (uint32_t)tk_popc64(IB & tk_lowmask(lane));
-            if (ins && at < ml->cap) {
-                uint32_t k[4];
+        bool ins = mine && np <= TK_MEMO_MAXIDS;
+        uint32_t k[4] = {0u, 0u, 0u, 0u};
+        tk_memo_entry* slot = nullptr;
+        if (wv_ballot(ins) && ml->n < ml->cap) {
+            if (ins) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int keep = (int)len - 4 * q;
                     k[q] = (q < N / 4 && keep > 0) ? (kk[q < N / 4 ? q : 0] & (keep >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u))) : 0u;
                 }
+                slot = a.memo_tab + (tk_memo_slot(tk_key_hash(t.key_hash_mode, k[0], k[1], k[2], k[3], len)) & a.memo_mask);
+                // a slot that already carries a claim of THIS call (a record index: no tag bit; the commit kernel leaves every claimed
+                // slot tagged) is most often the same word merged somewhere else a moment ago -- a new word comes in hundreds of lanes:
+                // no second record for it (a colliding word waits a call).  The load may be stale: then there is a duplicate, as before.
+                // Only on the call that fills an empty table (no look-ups yet: EVERY merged piece comes here, and the hot words would fill
+                // the log with copies of themselves -- with the check the second batch already runs warm, 2.32 -> 1.54 ms); later calls
+                // log only what the table missed, and the extra gather would cost them 2 %.
+                if (a.memo_probe == 0u) {
+                    const uint32_t cw = slot->w4;
+                    if (cw != 0u && (cw & TK_MEMO_TAG) == 0u) ins = false;
+                }
+            }
+        }
+        const uint64_t IB = wv_ballot(ins);
+        if (IB && ml->n < ml->cap) {
+            const uint32_t at = ml->n + (uint32_t)tk_popc64(IB & tk_lowmask(lane));
+            if (ins && at < ml->cap) {
                 uint32_t r5[5] = {0u, 0u, 0u, 0u, 0u};
                 alive_t rem = alive;
 #pragma unroll
@@ -1552,7 +1568,7 @@ TK_DEV uint32_t tk_merge_lds(const TkFlatArgs& a, const uint32_t* filt, bool min
                 // ... and CLAIMS its slot: the record's index into the slot's claim word, a plain store -- of all the records that want
                 // a slot in this call one index stays, and tk_memo_commit_kernel lets that record write (nothing reads the table
                 // while the merge and commit kernels run)
-                a.memo_tab[tk_memo_slot(tk_key_hash(t.key_hash_mode, k[0], k[1], k[2], k[3], len)) & a.memo_mask].w4 = (uint32_t)(w - a.memo_log);
+                slot->w4 = (uint32_t)(w - a.memo_log);
             }
             const uint32_t nn = ml->n + (uint32_t)tk_popc64(IB);
             ml->n = nn < ml->cap ? nn : ml->cap;

@@ -125,9 +125,9 @@ def memo_set(log2):
 
 
 def memo_info():
-    out = np.zeros(3, np.uint64)
+    out = np.zeros(5, np.uint64)
     lib().emu_memo_info(_p(out, ctypes.c_uint64))
-    return dict(calls=int(out[0]), hits_last=int(out[1]), entries=int(out[2]))
+    return dict(calls=int(out[0]), hits_last=int(out[1]), entries=int(out[2]), logged_last=int(out[3]), won_last=int(out[4]))
 
 
 def table_info(token_bytes, num_special):

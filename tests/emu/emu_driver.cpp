@@ -97,9 +97,10 @@ extern "C" int emu_encode_batch(const uint8_t* blob, const uint32_t* offs, uint3
 }
 
 // MEMO (tk_hash.h) on the emulator: a table the test owns, kept across emu_flat_encode_batch calls like the context's across
-// tk_encode_batch calls (log2 = 0: off).  emu_memo_info: {calls that used it, hits of the last call, valid entries}.
+// tk_encode_batch calls (log2 = 0: off).  emu_memo_info: {calls that used it, hits of the last call, valid entries, records the last
+// call logged, records of the last call that won their slot}.
 static tk_memo_entry* g_memo = nullptr;
-static uint32_t g_memo_mask = 0, g_memo_epoch = 0, g_memo_hits = 0, g_memo_log_cap = 0;
+static uint32_t g_memo_mask = 0, g_memo_epoch = 0, g_memo_hits = 0, g_memo_log_cap = 0, g_memo_logged = 0, g_memo_won = 0;
 extern "C" void emu_memo_set(uint32_t* table_words, uint32_t log2) {
     g_memo = log2 ? reinterpret_cast<tk_memo_entry*>(table_words) : nullptr;
     g_memo_mask = log2 ? (1u << log2) - 1u : 0u;
@@ -107,7 +108,7 @@ extern "C" void emu_memo_set(uint32_t* table_words, uint32_t log2) {
     g_memo_epoch = 0; g_memo_hits = 0;
 }
 extern "C" void emu_memo_info(uint64_t* out) {
-    out[0] = g_memo_epoch; out[1] = g_memo_hits; out[2] = 0;
+    out[0] = g_memo_epoch; out[1] = g_memo_hits; out[2] = 0; out[3] = g_memo_logged; out[4] = g_memo_won;
     if (g_memo) for (uint32_t i = 0; i <= g_memo_mask; ++i) out[2] += tk_memo_len(g_memo[i].v[2]) != 0u;
 }
 
@@ -280,8 +281,11 @@ extern "C" int emu_flat_encode_batch(const uint8_t* blob, const uint32_t* offs, 
     }
     if (fa.memo_tab) {                                      // tk_memo_commit_kernel
         const uint32_t nl = fa.memo_log_per_wave * fa.memo_log_waves;
+        g_memo_logged = g_memo_won = 0;
         for (uint32_t i = 0; i < nl; ++i) {
             if (!tk_memo_log_live(memo_log_counts.data(), fa.memo_log_per_wave, i)) continue;
+            ++g_memo_logged;
+            g_memo_won += fa.memo_tab[tk_memo_slot_of(memo_log[i], fa.t.key_hash_mode, fa.memo_mask)].w4 == i;
             if (!(memo_log[i].w4 & TK_MEMO_TAG) || tk_memo_n(memo_log[i].v[2]) == 0u || tk_memo_n(memo_log[i].v[2]) > TK_MEMO_MAXIDS) { g_err = "memo log: malformed record " + std::to_string(i) + " w4=" + std::to_string(memo_log[i].w4) + " v2=" + std::to_string(memo_log[i].v[2]) + " counts=" + std::to_string(memo_log_counts[i / fa.memo_log_per_wave]); return TK_ERR_RUNTIME; }
         }
         for (uint32_t i = 0; i < nl; ++i)

@@ -58,6 +58,8 @@ def main():
             docs.append(s.encode("utf-8", "ignore"))
         bos, eos = rng.random() < 0.5, rng.random() < 0.5
         data, offs = tk.pack_docs(docs)
+        if rng.random() < 0.03:
+            eng.memo_clear()          # (the next call fills an empty memo table again: its own path in the merge kernel)
         ids, oo = eng.encode_batch(data, offs, bos, eos)
         eids, eoo = orc.encode_batch(data, offs, bos, eos, threads=8)
         if not (np.array_equal(oo, eoo) and np.array_equal(ids, eids)):

@@ -42,7 +42,9 @@
 #define TKF_NHL (TKF_HL / TKF_W)                     /* lanes of the left halo: 2 / 1 */
 /* entries of the LDS piece list.  16 bytes per lane: every byte could start a piece.  32 bytes per lane: a chunk with
    more pieces than this (an average of under two bytes per piece over 2 KB) is handed back as a whole */
+#ifndef TKF_LISTCAP
 #define TKF_LISTCAP 1056
+#endif
 #define TKF_MAXPIECES (TKF_LISTCAP - 2)              /* + the sentinel */
 
 // LDS words of one wave
@@ -495,13 +497,14 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     uint32_t x[TKF_W / 4];
     for (int k = 0; k < TKF_W / 4; ++k) x[k] = 0u;
     {
+        const uint8_t* bytes = WV_KARGS(TkFlatArgs, a).bytes;
         const int64_t g = r0 + TKF_W * lane;
         if (g >= 0 && g + TKF_W <= n) {
-            for (int k = 0; k < TKF_W / 16; ++k) wv_load16(a.bytes + g + 16 * k, x + 4 * k);
+            for (int k = 0; k < TKF_W / 16; ++k) wv_load16(bytes + g + 16 * k, x + 4 * k);
         } else if (g + TKF_W > 0 && g < n) {
             for (int k = 0; k < TKF_W; ++k) {
                 const int64_t q = g + k;
-                if (q >= 0 && q < n) x[k >> 2] |= (uint32_t)a.bytes[q] << (8 * (k & 3));
+                if (q >= 0 && q < n) x[k >> 2] |= (uint32_t)bytes[q] << (8 * (k & 3));
             }
         }
     }
@@ -685,14 +688,15 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     lds[TKF_L_DS + lane] = 0u;
     lds[TKF_L_BAD + lane] = 0u;
     wv_lds_sync();
-    const uint64_t fd = a.first_doc[c];          // documents that start below max(r0, 0)
+    const uint64_t fd = WV_KARGS(TkFlatArgs, a).first_doc[c];          // documents that start below max(r0, 0)
     bool starts_at_r1 = false;
     {
         // documents d >= fd start at or above the region start; d == n_docs stands for the end of the stream
+        const auto& ka = WV_KARGS(TkFlatArgs, a);
         for (uint64_t base = fd;; base += 64) {
             const uint64_t d = base + (uint64_t)lane;
             int64_t s = INT64_MAX;
-            if (d <= a.n_docs) s = (int64_t)a.doc_offs[d];
+            if (d <= ka.n_docs) s = (int64_t)ka.doc_offs[d];
             const bool in = s < r1;
             if (in) wv_lds_or(lds + TKF_L_DS + ((s - r0) >> TKF_LOGW), 1u << ((s - r0) & (TKF_W - 1)));
             if (s == r1) starts_at_r1 = true;
@@ -871,8 +875,8 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         np_all = tot & 0xFFFFu; np_own = tot >> 16;
     }
     const int npass = np_all > TKF_MAXPIECES ? 2 : 1;
-    uint32_t* tmp = a.tmp + c * TKF_STRIDE;
-    uint32_t* mq = a.miss_list + c * TKF_MISSCAP;
+    uint32_t* tmp = WV_KARGS(TkFlatArgs, a).tmp + c * TKF_STRIDE;
+    uint32_t* mq = WV_KARGS(TkFlatArgs, a).miss_list + c * TKF_MISSCAP;
     uint32_t E = 0;                                         // slots beyond one per piece so far
     uint32_t base_own = 0;                                  // pieces of the earlier pass
     uint32_t nm0 = 0, nm1 = 0, nm2 = 0, nm3 = 0;
@@ -881,12 +885,13 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     auto doc_outputs = [&](bool want_flags, bool anybad) {
         // documents that touch the commit range: fd - 1 (the one that contains the region start) onwards
         const uint64_t dfirst = fd > 0 ? fd - 1 : 0;
+        const auto& ka = WV_KARGS(TkFlatArgs, a);           // (n_docs, doc_offs, lstart, flags: read here, not kept in scalar registers)
         for (uint64_t base = dfirst;; base += 64) {
             const uint64_t d = base + (uint64_t)lane;
             int64_t s = INT64_MAX, e = INT64_MAX;
-            if (d < a.n_docs) {
-                s = (int64_t)a.doc_offs[d];
-                e = (int64_t)a.doc_offs[d + 1];
+            if (d < ka.n_docs) {
+                s = (int64_t)ka.doc_offs[d];
+                e = (int64_t)ka.doc_offs[d + 1];
             }
             const bool in = s < c1;
             if (in && s >= c0) {
@@ -895,7 +900,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                 const uint32_t pl = p >> TKF_LOGW;
                 if (npass == 1 || (pl >= lane_lo && pl < lane_hi)) {
                     const uint32_t pi = lds[TKF_L_PFX + pl] + (uint32_t)__builtin_popcount(lds[TKF_L_PS + pl] & ((1u << (p & (TKF_W - 1))) - 1u));
-                    a.lstart[d] = pi < np_own ? list[pi] : base_own + np_own + E;
+                    ka.lstart[d] = pi < np_own ? list[pi] : base_own + np_own + E;
                 }
             }
             if (want_flags && anybad && in && e > c0) {
@@ -907,7 +912,7 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
                     uint32_t ch;
                     if (ph >= TKF_REGION) ch = lds[TKF_L_BPFX + 63] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + 63]);
                     else ch = lds[TKF_L_BPFX + (ph >> TKF_LOGW)] + (uint32_t)__builtin_popcount(lds[TKF_L_BAD + (ph >> TKF_LOGW)] & ((1u << (ph & (TKF_W - 1))) - 1u));
-                    if (ch > cl) a.flags[d] = 1u;
+                    if (ch > cl) ka.flags[d] = 1u;
                 }
             }
             if (wv_ballot(in) != ~0ull) break;
@@ -992,7 +997,8 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             } else if (len - 2u <= 14u) {                   // 2..16 bytes: exact-key probe
                 const uint32_t* kc = lds + TKF_L_CONST;
                 const uint64_t b8 = (uint64_t)kc[2] | ((uint64_t)kc[3] << 32), b16 = (uint64_t)kc[4] | ((uint64_t)kc[5] << 32);
-                r = tk_probe_key_h(wv_global_ptr(b8), kc[0], wv_global_ptr(b16), kc[1],
+                // (timing only, 512: the probes stay inside the first 1 / 16 of either table -- what the look-up would cost if the tables fitted the L2)
+                r = tk_probe_key_h(wv_global_ptr(b8), TKF_ABL(a, 512) ? kc[0] >> 4 : kc[0], wv_global_ptr(b16), TKF_ABL(a, 512) ? kc[1] >> 4 : kc[1],
                                    h, kk[0], kk[1], kk[2], kk[3], len);
             }
         }
@@ -1170,11 +1176,12 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
     }
   }
     if (lane == 0) {
-        a.kcount[c] = base_own + np_own + E;
-        a.miss_count[c] = nm0;                       // class-major: class k of chunk c at [k * n_chunks + c]
-        a.miss_count[a.n_chunks + c] = nm1;
-        a.miss_count[2 * a.n_chunks + c] = nm2;
-        a.miss_count[3 * a.n_chunks + c] = nm3;
+        const auto& ka = WV_KARGS(TkFlatArgs, a);
+        ka.kcount[c] = base_own + np_own + E;
+        ka.miss_count[c] = nm0;                      // class-major: class k of chunk c at [k * n_chunks + c]
+        ka.miss_count[ka.n_chunks + c] = nm1;
+        ka.miss_count[2 * ka.n_chunks + c] = nm2;
+        ka.miss_count[3 * ka.n_chunks + c] = nm3;
     }
 
     // ---- 7. per-document outputs: slot of every document start, fall-back flags ---------------------

@@ -126,6 +126,19 @@ TK_DEV const uint8_t* wv_global_ptr(uint64_t addr) {
     return (const uint8_t*)reinterpret_cast<gptr_t>(addr);
 }
 
+// The kernel's argument block (the struct the kernel takes by value as its FIRST parameter), opaque to the optimiser from here on: a
+// field read through the result is a scalar load from the kernarg segment that stays where it is written.  Read through the
+// parameter itself, every field is loaded at the kernel's entry and lives in scalar registers from there on -- a long kernel then
+// spills them to VGPR lanes (v_writelane / v_readlane: VALU instructions of the dear kind) where a reload costs no VALU issue at all.
+#define WV_KARGS(T, a) (*wv_kargs_fresh<T>())
+template <class T>
+TK_DEV const T __attribute__((address_space(4))) * wv_kargs_fresh() {
+    typedef const T __attribute__((address_space(4))) * kptr_t;
+    kptr_t p = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // "this value is needed HERE": keeps the compiler from sinking the load that produces it behind a later branch (it
 // otherwise turns independent loads into a chain of conditional ones -- each a full memory round trip)
 #define WV_PIN(x) asm volatile("" : "+v"(x))

@@ -323,6 +323,7 @@ TK_DEV void wv_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 TK_DEV void wv_lds_and64(uint64_t* p, uint64_t v) { *p &= v; }
 
 TK_DEV void wv_load16(const uint8_t* p, uint32_t* x) { memcpy(x, p, 16); }
+#define WV_KARGS(T, a) (a)
 TK_DEV void wv_store16(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 TK_DEV uint32_t wv_scan_incl_u32(uint32_t v) {

@@ -53,5 +53,6 @@ echo "load time done"
 timeout -k 10 200 python tools/gpu_longpiece_time.py > $out/longpiece_time_${tag}.txt 2> /dev/null || exit 1
 echo "long piece timing done"
 timeout -k 10 300 python tools/pattern_time.py > $out/pattern_time_${tag}.json 2> /dev/null || exit 1
+KIND=mixed DOC_LEN=2048 N_DOCS=100000 timeout -k 10 300 python tools/pattern_time.py >> $out/pattern_time_${tag}.json 2> /dev/null || exit 1
 echo "JSON pattern timing done"
 echo "all done"

@@ -431,9 +431,10 @@ def main():
             out.update(cpu_baseline(a2, data, offs, vocab_path, v_i, v_o, n_bytes))
         if distributed:
             out["link_model"] = link_model(world, per_rank, total_ids, total_docs, 18 if codec else 32, ms_per_step)
+        if not distributed and args.extra_legs == "auto" and args.kind == "ascii" and not args.vocab and args.vocab_fit == "same" and not fresh:
+            out["two_in_flight"] = in_flight_leg(tk, vocab_path, eng, d_bytes, d_offs, n_docs, n_bytes, ms_per_step, calls=100 if n_docs >= 500_000 else 10)
         if not distributed and args.extra_legs == "auto" and args.kind == "ascii" and not args.vocab and args.vocab_fit == "same" \
                 and n_docs == 1_000_000 and args.doc_len == 512 and not fresh:
-            out["two_in_flight"] = in_flight_leg(tk, vocab_path, eng, d_bytes, d_offs, n_docs, n_bytes, ms_per_step)
             tokz.close()
             tokz = None
             del d_bytes, d_offs

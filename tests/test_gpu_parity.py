@@ -378,6 +378,8 @@ def test_bench_contract_small(tk):
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and "workload" in j["config"]
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["bit_exact_vs_cpu"] is True
     assert j["decode"]["round_trip_exact"] is True
+    # two contexts fed by two host threads (the leg that shows what a second batch in flight buys): both give the same ids
+    assert j["two_in_flight"]["both_contexts_same_ids"] is True and j["two_in_flight"]["calls_timed"] == 20
 
 
 def test_table_cache_context(tk, bench_vocab, tmp_path, monkeypatch):

@@ -119,7 +119,9 @@ struct tk_ctx {
     bool no_flat_cut = false;      // TK_FLAT_CUT=0: no cut decomposition (pieces of more than 256 bytes hand their documents back; A / B and tests)
     int pattern = 0;               // tk_ctx_set_pattern: 0 the reference's hard-coded pattern, 1 the JSON pattern (row f-3)
     bool have_specials = false;
-    DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi;
+    DevBuf dec_lens, dec_bytes, dec_offs, dec_bits, dec_err, dec_in_ids, dec_in_offs, dec_hi, dec_glens, dec_goffs;
+    bool no_decode_groups = false;   // TK_DECODE_GROUPS=0: the per-document length pass (A / B and tests of the fall-back)
+    uint32_t decode_group_limit = 0x7FFFFF00u;   // ids / text bytes of a group from which the call falls back (TK_DECODE_GROUP_LIMIT: tests)
     DevBuf t_inline, t_len8;   // decode: 16-byte inline entries and one-byte lengths by rank (built at the first decode call)
     DevBuf staging, counts, out_ids, out_offs, block_sums, defer_list, scratch, counters, in_bytes, in_offs, dbg;
     DevBuf f_long;             // flat path: records of the pieces of 65..TKF_LONGCAP bytes
@@ -235,6 +237,8 @@ extern "C" int tk_ctx_create(const uint8_t* token_bytes, const uint32_t* token_o
     for (int i = 0; i < 3; ++i)
         if (hipEventCreateWithFlags(&c->ev_b[i], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(TK_ERR_RUNTIME); }
     if (const char* tl = getenv("TK_TAIL")) c->serial_tail = strcmp(tl, "serial") == 0;
+    if (const char* dg = getenv("TK_DECODE_GROUPS")) c->no_decode_groups = strcmp(dg, "0") == 0;
+    if (const char* gl = getenv("TK_DECODE_GROUP_LIMIT")) { const long long v = atoll(gl); if (v > 0 && v < 0x7FFFFF00ll) c->decode_group_limit = (uint32_t)v; }
     if (hipHostMalloc((void**)&c->h_pin, 256, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return fail(TK_ERR_RUNTIME); }
 
     const TkHostTables& h = c->host;
@@ -309,7 +313,7 @@ extern "C" void tk_ctx_destroy(tk_ctx* c) {
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->t_key64, &c->t_ucbmp, &c->t_cutk2, &c->t_cutg3, &c->f_cut, &c->t_uc2a, &c->t_uc2b, &c->t_uc1, &c->t_uc2, &c->t_key8, &c->t_key, &c->t_long, &c->t_pair, &c->t_pair2, &c->t_pairf, &c->t_blob, &c->t_offs,
                       &c->t_spblob, &c->t_spoffs, &c->dec_lens, &c->dec_bytes, &c->dec_offs, &c->dec_bits,
-                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->t_inline, &c->t_len8,
+                      &c->dec_err, &c->dec_in_ids, &c->dec_in_offs, &c->dec_hi, &c->dec_glens, &c->dec_goffs, &c->t_inline, &c->t_len8,
                       &c->staging, &c->counts, &c->out_ids, &c->out_offs, &c->block_sums, &c->defer_list,
                       &c->scratch, &c->long_list, &c->long_jobs, &c->f_long, &c->counters, &c->in_bytes, &c->in_offs, &c->dbg,
                       &c->f_first, &c->f_tmp, &c->f_lstart, &c->f_flags, &c->f_todo, &c->f_miss, &c->f_mcnt, &c->f_mpfx, &c->f_wfirst, &c->f_info};
@@ -1553,15 +1557,36 @@ static int run_decode(tk_ctx* c, const uint32_t* d_ids, const uint64_t* d_id_off
     a.n_ranks = c->host.n_ranks;
     a.num_special = c->host.num_special;
     a.policy = policy;
-    TK_HIP(c, hipMemsetAsync(c->dec_err.p, 0xFF, 24, s));
+    // Lengths by GROUPS of 16 documents (tk_decode_grouplen_kernel): the emit kernel only needs to know where a group's text begins
+    // and writes the documents' offsets itself.  A group whose text reaches 4 GiB (err[3]) sends the call through the per-document
+    // length pass instead.
+    const uint64_t n_groups = (n_docs + TK_DECODE_GROUP_DOCS - 1) / TK_DECODE_GROUP_DOCS;
+    TK_HIP(c, c->dec_glens.reserve((n_groups + 1) * 4));
+    TK_HIP(c, c->dec_goffs.reserve((n_groups + 2) * 8));
+    a.glens = (uint32_t*)c->dec_glens.p;
+    a.group_limit = c->decode_group_limit;
+    TK_HIP(c, hipMemsetAsync(c->dec_err.p, 0xFF, 32, s));
     TK_HIP(c, hipEventRecord(c->ev[0], s));
-    TK_HIP(c, tk_launch_decode_doclen(a, s));
-    TK_HIP(c, tk_launch_scan(a.lens, n_docs, (uint64_t*)c->dec_offs.p, (uint64_t*)c->block_sums.p, s));
     uint64_t total = 0;
-    unsigned long long err[3] = {~0ull, ~0ull, ~0ull};
-    TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 16, hipMemcpyDeviceToHost, s));
-    TK_HIP(c, hipStreamSynchronize(s));
+    unsigned long long err[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    const bool by_groups = !c->no_decode_groups;
+    if (by_groups) {
+        TK_HIP(c, tk_launch_decode_grouplen(a, s));
+        TK_HIP(c, tk_launch_scan(a.glens, n_groups, (uint64_t*)c->dec_goffs.p, (uint64_t*)c->block_sums.p, s));
+        TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_goffs.p + n_groups, 8, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 32, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+        if (n_docs == 0) total = 0;
+    }
+    if (by_groups && err[3] == ~0ull) {
+        a.goffs = (const uint64_t*)c->dec_goffs.p;
+    } else {
+        TK_HIP(c, tk_launch_decode_doclen(a, s));
+        TK_HIP(c, tk_launch_scan(a.lens, n_docs, (uint64_t*)c->dec_offs.p, (uint64_t*)c->block_sums.p, s));
+        TK_HIP(c, hipMemcpyAsync(&total, (uint64_t*)c->dec_offs.p + n_docs, 8, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipMemcpyAsync(err, c->dec_err.p, 16, hipMemcpyDeviceToHost, s));
+        TK_HIP(c, hipStreamSynchronize(s));
+    }
     auto doc_of = [&](uint64_t id_index, uint64_t* out) -> int {
         // first document whose id range contains id_index: binary search on the device offsets (rare path)
         uint64_t lo = 0, hi = n_docs;

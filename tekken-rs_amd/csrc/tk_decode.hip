@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t tkd_scan_incl(uint32_t v) {
     return x;
 }
 
-#define TKD_DOCS 16u          /* consecutive documents a wave takes as one stream of ids */
+#define TKD_DOCS TK_DECODE_GROUP_DOCS          /* consecutive documents a wave takes as one stream of ids */
 #define TKD_L8_LDS 32768u     /* one-byte lengths of the ranks below this live in LDS (99 % of the ids of running text) */
 
 // pass A: the text length of every document + error flags: one wave per document, one lane per id; the length of a token
@@ -100,6 +100,59 @@ __global__ __launch_bounds__(TKD_LEN_BLOCK) void tk_decode_doclen_kernel(TkDecod
     }
 }
 
+// pass A, the form the pipeline uses: the text length of every GROUP of TKD_DOCS consecutive documents -- all the emit kernel needs
+// to know where a group's text begins (it places the documents inside the group itself and writes their offsets).  One wave per
+// group, the group's ids as one coalesced stream, four loads in flight per lane, ONE reduction per group: 0.5 instructions per id
+// where the per-document pass above spends 2 (its ~150 instructions of overhead per document are 98 ids' worth on the C2 shape).
+// Error flags as above; err[3] is set when a group's text reaches 4 GiB (the scan takes 32-bit lengths): the host then falls
+// back to the per-document pass.
+__global__ __launch_bounds__(TKD_LEN_BLOCK) void tk_decode_grouplen_kernel(TkDecodeArgs a) {
+    __shared__ uint32_t l8w[TKD_L8_LDS / 4];
+    const uint32_t n_lds = a.n_ranks < TKD_L8_LDS ? a.n_ranks : TKD_L8_LDS;
+    for (uint32_t q = threadIdx.x; q < (n_lds + 3u) / 4u; q += TKD_LEN_BLOCK) l8w[q] = reinterpret_cast<const uint32_t*>(a.tok_len8)[q];
+    __syncthreads();
+    const uint8_t* l8 = reinterpret_cast<const uint8_t*>(l8w);
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (TKD_LEN_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (TKD_LEN_BLOCK / 64);
+    const uint64_t n_groups = (a.n_docs + TKD_DOCS - 1) / TKD_DOCS;
+    auto id_len = [&](uint32_t id, uint64_t i) -> uint32_t {
+        if (id < a.num_special) {
+            if (a.policy == TK_POLICY_RAISE) atomicMin(a.err + 0, (unsigned long long)i);
+            return a.policy == TK_POLICY_KEEP ? a.sp_offs[id + 1] - a.sp_offs[id] : 0u;
+        }
+        const uint32_t r = id - a.num_special;
+        if (r >= a.n_ranks) {
+            atomicMin(a.err + 1, (unsigned long long)i);
+            return 0u;
+        }
+        uint32_t len = r < TKD_L8_LDS ? (uint32_t)l8[r] : (uint32_t)a.tok_len8[r];
+        if (len == 0xFFu) len = a.tok_offs[r + 1] - a.tok_offs[r];
+        return len;
+    };
+    for (uint64_t g = wave; g < n_groups; g += n_waves) {
+        const uint64_t dA = g * TKD_DOCS, dB = dA + TKD_DOCS < a.n_docs ? dA + TKD_DOCS : a.n_docs;
+        const uint64_t i0 = a.id_offs[dA], i1 = a.id_offs[dB];
+        uint64_t acc = 0;
+        uint64_t i = i0 + (uint64_t)lane;
+        for (; i + 192 < i1; i += 256) {
+            const uint32_t v0 = a.ids[i], v1 = a.ids[i + 64], v2 = a.ids[i + 128], v3 = a.ids[i + 192];
+            acc += (uint64_t)id_len(v0, i) + id_len(v1, i + 64) + id_len(v2, i + 128) + id_len(v3, i + 192);
+        }
+        for (; i < i1; i += 64) acc += id_len(a.ids[i], i);
+        // 64-bit sum over the lanes (butterfly)
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)acc, sh), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), sh);
+            acc += ((uint64_t)ohi << 32) | olo;
+        }
+        const uint64_t tot = acc;
+        if (lane == 0) {
+            a.glens[g] = (uint32_t)tot;
+            if (tot >= (uint64_t)a.group_limit || i1 - i0 >= (uint64_t)a.group_limit) atomicMin(a.err + 3, (unsigned long long)g);
+        }
+    }
+}
+
 // pass B: one wave per document.  64 ids at a time: an in-register prefix sum places every token inside the
 // chunk's byte span, lanes scatter their token bytes into a per-wave LDS image of that span (byte writes
 // stay on chip), and the wave streams the image to HBM with aligned, coalesced dword stores; only the
@@ -116,6 +169,7 @@ __device__ __forceinline__ tkd_u32x4 tkd_entry(const TkDecodeArgs& a, uint32_t i
     return v;
 }
 
+template <bool GROUPS>
 __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs a) {
     __shared__ uint32_t img_all[(TKD_BLOCK / 64) * (TKD_IMG_BYTES / 4 + 2)];
     const int lane = threadIdx.x & 63;
@@ -130,7 +184,21 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
     for (uint64_t dA = wave * TKD_DOCS; dA < a.n_docs; dA += n_waves * TKD_DOCS) {
         const uint64_t dB = dA + TKD_DOCS < a.n_docs ? dA + TKD_DOCS : a.n_docs;
         const uint64_t i0 = a.id_offs[dA], i1 = a.id_offs[dB];
-        uint64_t cursor = a.out_offs[dA];
+        uint64_t cursor = GROUPS ? a.goffs[dA / TKD_DOCS] : a.out_offs[dA];
+        // Group mode (goffs): the documents' own offsets come from HERE -- a document begins where the step's prefix sum puts its
+        // first id.  Lane j < 16 keeps ONE word for document dA + j: the distance of its first id from the group's first one (31
+        // bits: the length pass sends a group of 2^31 ids or bytes down the other path), then -- bit 31 set -- where its text begins
+        // in the group's text; jn / nrel: the next document whose start has not been seen, wave-uniform (the starts are in order).
+        // One coalesced store of the 16 offsets per group.  (Costs the kernel its eighth wave per SIMD: 72 VGPRs against 60, 0.75
+        // against 0.68 ms on the C2 shape -- and saves 0.13 of the length pass's 0.26.)
+        const uint32_t ndg = (uint32_t)(dB - dA);
+        uint32_t dword = 0x7FFFFFFFu;               // lanes past the group's documents: "never"
+        const uint64_t gstart = cursor;
+        if (GROUPS && (uint32_t)lane < ndg) {
+            const uint64_t ds = a.id_offs[dA + (uint64_t)lane];
+            dword = ds < i1 ? (uint32_t)(ds - i0) : 0x7FFFFFFEu;     // (0x7FFFFFFE: an empty document at the group's very end)
+        }
+        uint32_t jn = 0, nrel = GROUPS ? (uint32_t)__builtin_amdgcn_readlane((int)dword, 0) : 0x7FFFFFFFu;
         bool hi_any = false;                       // some byte >= 0x80 among the token bytes this lane emitted
         uint32_t id0 = i0 + (uint64_t)lane < i1 ? a.ids[i0 + lane] : 0u;
         uint32_t id1 = i0 + 64 + (uint64_t)lane < i1 ? a.ids[i0 + 64 + lane] : 0u;
@@ -237,8 +305,26 @@ __global__ __launch_bounds__(TKD_BLOCK) void tk_decode_emit_kernel(TkDecodeArgs 
                     hi_any |= bk >= 0x80u;
                 }
             }
+            if (GROUPS) {
+                // documents whose first id is one of this step's 64 (scalar loop: jn, nrel are wave-uniform)
+                const uint32_t srel = (uint32_t)(c0 - i0);
+                while (nrel - srel < 64u) {
+                    // (a lane past the group's last id has len 0 and the whole span in front of it)
+                    const uint32_t at = (uint32_t)(cursor - gstart) + (uint32_t)__builtin_amdgcn_readlane((int)(incl - len), (int)(nrel - srel));
+                    if ((uint32_t)lane == jn) dword = 0x80000000u | at;
+                    ++jn;
+                    nrel = jn < ndg ? (uint32_t)__builtin_amdgcn_readlane((int)dword, (int)(jn & 63u)) : 0x7FFFFFFFu;
+                }
+            }
             cursor = end;
             id0 = id1; id1 = id2; e0 = e1;
+        }
+        if (GROUPS) {
+            // empty documents at the end of the group begin where its text ends; the last group also writes the grand total
+            // (what was not seen in the loop: empty documents at the group's very end -- they begin where its text ends)
+            const uint32_t myoff = (dword & 0x80000000u) ? (dword & 0x7FFFFFFFu) : (uint32_t)(cursor - gstart);
+            if ((uint32_t)lane < ndg) a.out_offs[dA + (uint64_t)lane] = gstart + myoff;
+            if (dB == a.n_docs && lane == 0) a.out_offs[a.n_docs] = cursor;
         }
         const bool doc_hi = __ballot(hi_any) != 0ull;   // ASCII documents need no UTF-8 validation pass (decided per group)
         if (dA + (uint64_t)lane < dB) a.doc_hi[dA + lane] = doc_hi ? 1u : 0u;
@@ -314,9 +400,19 @@ hipError_t tk_launch_decode_doclen(const TkDecodeArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t tk_launch_decode_grouplen(const TkDecodeArgs& a, hipStream_t s) {
+    if (a.n_docs == 0) return hipSuccess;
+    const uint64_t n_groups = (a.n_docs + TKD_DOCS - 1) / TKD_DOCS;
+    uint64_t blocks = (n_groups + TKD_LEN_BLOCK / 64 - 1) / (TKD_LEN_BLOCK / 64);
+    if (blocks > 256u * 2u) blocks = 256u * 2u;             // every block copies 32 KB into its LDS first: no more than are resident
+    hipLaunchKernelGGL(tk_decode_grouplen_kernel, dim3((uint32_t)blocks), dim3(TKD_LEN_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t tk_launch_decode_emit(const TkDecodeArgs& a, hipStream_t s) {
     if (a.n_docs == 0) return hipSuccess;
-    hipLaunchKernelGGL(tk_decode_emit_kernel, dim3(tkd_doc_grid((a.n_docs + TKD_DOCS - 1) / TKD_DOCS)), dim3(TKD_BLOCK), 0, s, a);
+    if (a.goffs) hipLaunchKernelGGL(tk_decode_emit_kernel<true>, dim3(tkd_doc_grid((a.n_docs + TKD_DOCS - 1) / TKD_DOCS)), dim3(TKD_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(tk_decode_emit_kernel<false>, dim3(tkd_doc_grid((a.n_docs + TKD_DOCS - 1) / TKD_DOCS)), dim3(TKD_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 

@@ -67,11 +67,15 @@ hipError_t tk_launch_pack18(const uint32_t* ids, uint64_t n, void* packed, uint3
 hipError_t tk_launch_unpack18(const void* packed, uint64_t n, uint32_t* ids, hipStream_t s);
 
 // ---- decode path (tk_decode.hip) ----
+#define TK_DECODE_GROUP_DOCS 16u   /* consecutive documents the decode kernels take as one stream of ids */
 struct TkDecodeArgs {
     const uint32_t* ids;       // [n_ids] packed token ids of all documents
     const uint64_t* id_offs;   // [n_docs + 1]
     uint64_t n_ids, n_docs;
-    uint32_t* lens;            // [n_docs] text bytes of every document
+    uint32_t* lens;            // [n_docs] text bytes of every document (per-document length pass: the fall-back form)
+    uint32_t* glens;           // [ceil(n_docs / 16)] text bytes of every group of 16 consecutive documents (tk_decode_grouplen_kernel)
+    const uint64_t* goffs;     // [groups + 1] exclusive scan of glens; non-NULL: the emit kernel starts a group there and writes out_offs itself
+    uint32_t group_limit;      // a group with this many ids or text bytes (< 2^31) raises err[3]: the call takes the per-document pass
     uint8_t* out_bytes;        // [total bytes]
     uint64_t* out_offs;        // [n_docs + 1] exclusive scan of lens
     uint32_t* run_bits;        // bitmap over output bytes: 1 = a run starts here (hard UTF-8 boundary)
@@ -87,6 +91,7 @@ struct TkDecodeArgs {
     int policy;                // TK_POLICY_*
 };
 hipError_t tk_launch_decode_doclen(const TkDecodeArgs& a, hipStream_t s);
+hipError_t tk_launch_decode_grouplen(const TkDecodeArgs& a, hipStream_t s);   // err[3] != ~0: a group's text reaches 4 GiB, use the per-document pass
 hipError_t tk_launch_decode_emit(const TkDecodeArgs& a, hipStream_t s);
 hipError_t tk_launch_decode_validate(const TkDecodeArgs& a, hipStream_t s);
 

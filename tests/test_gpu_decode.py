@@ -165,3 +165,51 @@ def test_utf8_validation_at_every_window_offset(tk, eng, test_vocab):
         # ... and the same bytes without the special id are fine
         ok = byte_ids(b"a" * k) + [ns + 0xE4, ns + 0xB8, ns + 0xAD] + byte_ids(b"b" * 9)
         assert eng.decode_docs([ok], P.Ignore) == [b"a" * k + "中".encode() + b"b" * 9]
+
+
+def test_length_pass_by_groups_and_by_documents_agree(tk, test_vocab, monkeypatch):
+    """The decode pipeline sizes its output from the text lengths of GROUPS of 16 documents (tk_decode_grouplen_kernel) and lets the
+    emit kernel place the documents inside a group; TK_DECODE_GROUPS=0 (and a group whose text reaches 2 GiB) takes the
+    per-document length pass instead.  Both forms give the reference's text and offsets: empty documents at the beginning, in the
+    middle and at the end of a group, groups of nothing but empty documents, a last group that is not full, special tokens under
+    every policy, documents much longer than a step."""
+    import random
+    rng = random.Random(5)
+    orc = helpers.oracle_for(test_vocab)
+    words = [b"hello", b" world", b"\n", b" caf\xc3\xa9", b" \xf0\x9f\x9a\x80", b"12", b" x"]
+    def doc():
+        k = rng.choice([0, 0, 1, 3, 40, 400, 3000])
+        return b"".join(rng.choice(words) for _ in range(k))
+    shapes = [[doc() for _ in range(n)] for n in (1, 15, 16, 17, 33, 100)]
+    shapes.append([b""] * 40)                                            # nothing but empty documents
+    shapes.append([b"a"] + [b""] * 31 + [b"b"] + [b""] * 15)             # whole groups of empty documents between two texts
+    shapes.append([b""] * 16 + [doc() for _ in range(16)] + [b""] * 5)
+    P = tk.SpecialTokenPolicy
+    engines = []
+    for groups, limit in (("1", ""), ("0", ""), ("1", "2000")):           # (the third: groups, but a group of 2000 bytes already falls back)
+        monkeypatch.setenv("TK_DECODE_GROUPS", groups)
+        if limit:
+            monkeypatch.setenv("TK_DECODE_GROUP_LIMIT", limit)
+        e = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+        e.set_special_tokens(SPECIALS)
+        engines.append(e)
+    try:
+        for docs in shapes:
+            for bos, eos in ((True, True), (False, False)):
+                id_lists = [orc.encode(d, bos, eos) for d in docs]
+                # a few special ids in the middle of some documents
+                for ids in id_lists[::3]:
+                    if len(ids) > 4:
+                        at = len(ids) // 2
+                        ids.insert(at, 3)
+                        try:
+                            ref(test_vocab, ids, P.Ignore)
+                        except ValueError:                               # (it cut a UTF-8 sequence into two runs: not this test's subject)
+                            del ids[at]
+                for policy in (P.Ignore, P.Keep):
+                    want = [ref(test_vocab, ids, policy) for ids in id_lists]
+                    for e in engines:
+                        assert e.decode_docs(id_lists, policy) == want
+    finally:
+        for e in engines:
+            e.close()

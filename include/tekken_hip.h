@@ -115,7 +115,8 @@ uint64_t tk_last_host_syncs(const tk_ctx* ctx);
  *                 measured on the held-out shape: 2^20 entries 0.66 of the look-ups hit, 2^22 0.77, 2^24 0.85: the table is direct-mapped)
  *   policy        0 = adaptive: after two calls in a row that hit less than once per 160 bytes of text or less than three times in
  *                 ten look-ups (text with few unknown pieces, or whose unknown pieces never come back) the table is left
- *                 alone for 30 calls, 1 = always on (TK_MEMO_POLICY=always)
+ *                 alone for 30 calls; a call of under 1 MB of text never uses it (a context that only sees such calls never
+ *                 allocates it).  1 = always on (TK_MEMO_POLICY=always)
  * tk_ctx_memo_clear empties the table.  tk_memo_stats: look-ups (pieces of 2..16 bytes that missed the vocabulary) and hits of
  * the last call and since the context was created, and whether the last call used the table. */
 int tk_ctx_set_memo(tk_ctx* ctx, int log2_entries, int policy);

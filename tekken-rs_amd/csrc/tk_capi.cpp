@@ -571,11 +571,14 @@ static int run_pipeline_doc(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* d
 // come back (random code points: BASELINE configs[2]) or that has few of them (a vocabulary fitted to the text), the look-ups cost
 // more than the hits return, so after two such calls in a row the table is left alone for 30 calls, then tried again.
 // Whatever the policy does, ids never depend on it: an entry is the exact key and the pure merge of its bytes.
-static int memo_prepare(tk_ctx* c, TkFlatArgs& fa, hipStream_t s) {
+static int memo_prepare(tk_ctx* c, TkFlatArgs& fa, hipStream_t s, uint64_t n_bytes) {
     fa.memo_tab = nullptr; fa.memo_mask = 0; fa.memo_epoch = 0; fa.memo_hits = nullptr;
     fa.memo_log = nullptr; fa.memo_log_counts = nullptr; fa.memo_log_per_wave = 0; fa.memo_log_waves = 0;
     c->memo_active_last = false;
     if (c->memo_log2 == 0) return TK_OK;
+    // adaptive policy: a call of under 1 MB leaves the table alone (and a context that only ever sees such calls never allocates
+    // its 576 MB): memo_account cannot judge a call that small, and its two extra launches are a tenth of its time
+    if (c->memo_policy == 0 && n_bytes < (1u << 20)) return TK_OK;
     if (c->memo_policy == 0 && c->memo_pause) { --c->memo_pause; return TK_OK; }
     const size_t bytes = ((size_t)1 << c->memo_log2) * sizeof(tk_memo_entry);
     if (c->memo_have_log2 != c->memo_log2) {
@@ -732,7 +735,7 @@ static int run_pipeline_flat(tk_ctx* c, const uint8_t* d_bytes, const uint64_t* 
     uint64_t* d_pfx = (uint64_t*)c->f_mpfx.p;                  // prefix sums over [4 C miss counts | C slot counts]
     const uint64_t* d_P = d_pfx + 4 * n_chunks;                // chunk slot prefix sums (offset by the miss total: only differences are used)
     TK_HIP(c, c->out_ids.reserve((n_bytes + 2 * n_docs + 64) * 4));
-    { int rcm = memo_prepare(c, fa, s); if (rcm != TK_OK) return rcm; }
+    { int rcm = memo_prepare(c, fa, s, n_bytes); if (rcm != TK_OK) return rcm; }
     TK_HIP(c, hipEventRecord(c->ev[3], s));
     // (the pre-pass also clears the per-document flags / holes and the 16 counter words: no memset launches)
     TK_HIP(c, tk_launch_flat_firstdoc(d_offs, n_docs, n_chunks, (uint32_t*)c->f_first.p, fa.flags, fa.holes, (uint32_t*)c->counters.p, s));

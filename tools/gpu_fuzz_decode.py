@@ -40,16 +40,16 @@ def main():
     def ref(ids, policy):
         return tk_oracle.decode_ref(v["tokens"], SPECIALS, ns, ids, policy)
 
-    def one_doc():
+    def one_doc(p_bad):
         k = rng.choice([0, 0, 1, 2, 10, 30, 63, 64, 65, 127, 128, 129, 400, 3000])
         ids = orc.encode(b"".join(rng.choice(words) for _ in range(k)), rng.random() < 0.5, rng.random() < 0.5)
         r = rng.random()
-        if r < 0.25 and ids:                                    # special ids somewhere
+        if r < 0.25 and ids:                                    # special ids somewhere (between whole tokens: they may still cut a byte-fallback sequence)
             for _ in range(rng.randint(1, 3)):
                 ids.insert(rng.randint(0, len(ids)), rng.randint(0, 5))
-        elif r < 0.30 and ids:                                  # a raw byte token: may cut or break a UTF-8 sequence
+        elif r < 0.25 + 0.7 * p_bad and ids:                    # a raw byte token: may cut or break a UTF-8 sequence
             ids.insert(rng.randint(0, len(ids)), ns + rng.randint(0x80, 0xFF))
-        elif r < 0.32:                                          # an id outside the vocabulary
+        elif r < 0.25 + p_bad:                                  # an id outside the vocabulary
             ids.insert(rng.randint(0, len(ids)), ns + nr + rng.randint(0, 9))
         return ids
 
@@ -57,7 +57,8 @@ def main():
     n_batches = n_docs = n_ids = n_err = 0
     while time.time() - t0 < a.seconds:
         nd = rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 48, 100, 257])
-        id_lists = [one_doc() for _ in range(nd)]
+        p_bad = rng.choice([0.0, 0.0, 0.0, 0.02, 0.2])              # most batches hold no document the reference rejects on purpose
+        id_lists = [one_doc(p_bad) for _ in range(nd)]
         if rng.random() < 0.2:                                  # runs of empty documents: whole groups of them, the batch's end
             at = rng.randint(0, len(id_lists))
             id_lists[at:at] = [[] for _ in range(rng.choice([1, 16, 17, 40]))]

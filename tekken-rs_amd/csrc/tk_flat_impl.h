@@ -754,7 +754,10 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
         // (the region may begin inside a code point: its leading continuation bytes have no class and count as part of the run)
         const uint32_t d0 = wv_readlane(DS, 0);
         const uint32_t n0 = wv_readlane(m.N | (m.U8C & ~(m.U8C + 1u)), 0);
-        const uint32_t l0 = wv_readlane(PAT ? (m.NL | m.SL) : m.NL, 0);   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
+        // (the CR / LF run counts the orphan continuation bytes too: whether the char they belong to was punctuation -- the run is
+        // then the tail its piece absorbs -- or white space is not known here.  Found by the GPU fuzz in round 4: U+3000, forty CRs,
+        // eleven TABs, a region that began inside the U+3000 -> the CRs looked absorbed and a piece began at the first TAB)
+        const uint32_t l0 = wv_readlane((PAT ? (m.NL | m.SL) : m.NL) | (m.U8C & ~(m.U8C + 1u)), 0);   // (JSON pattern: the absorbed tail runs through CR / LF / '/')
         const bool covered = n0 == TKF_WM || l0 == TKF_WM;
         if (r0 > 0 && d0 == 0u && covered && lane == TKF_NHL) BAD |= 1u;
         if (PAT) {

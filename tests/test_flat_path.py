@@ -77,6 +77,42 @@ def test_emu_flat_baseline_shapes(test_vocab):
         _emu_check(test_vocab, helpers.EDGE_DOCS, bos, eos)
 
 
+def test_crlf_run_behind_a_char_the_region_cuts(test_vocab):
+    """A region that begins INSIDE a multi-byte char cannot know that char's class: a CR / LF run right behind it is either the tail
+    its piece absorbs (the char was punctuation: `[^\\s\\p{L}\\p{N}]+[\\r\\n]*`) or part of a white-space run (it was U+3000) -- and the
+    pieces behind the run differ.  Where such a run covers the rest of the left halo the document is handed back (hand-back rule A;
+    found by the GPU fuzz of round 4: U+3000, forty CRs, eleven TABs, twenty-two CRs -- the CRs looked absorbed, a piece began at
+    the first TAB and the fragment behind it was emitted twice).  Every alignment of the char over the region start, both kinds
+    of char, run lengths around the halo, on the model and on the emulated kernel."""
+    tails = [b"\r" * 40 + b"\t" * 11 + b"\r" * 22 + b"'''''abc", b"\n" * 33 + b"  x", b"\r\n" * 20 + b"\t\ty", b"\r" * 30 + b" z", b"\n" * 64 + b"\t" * 3 + b"\n\nq"]
+    chars = ["\u3000".encode(), "\u2026".encode(), "\u00a0".encode(), "\U0001f680".encode(), "\u4e2d".encode()]   # white space, punctuation, NBSP, emoji, letter
+    docs = []
+    for region, commit in ((256, 160), (2048, 1952)):
+        for ch in chars:
+            for tail in tails:
+                for k in range(len(ch) + 1):
+                    # the char ends k bytes behind the start of the second region (= commit - 32)
+                    pad_len = commit - 32 - (len(ch) - k) + (commit if region == 256 else 0)
+                    pad = (b"ab cd\n" * 400)[:pad_len]
+                    doc = pad + ch + tail + b" tail of the document.\n" * 3
+                    if region == 256:
+                        deferred = _model_check([doc], region=256)
+                    docs.append(doc)
+    # the fuzz's own text: the white-space piece is 136 bytes long (cut into fragments), the region of the next chunk begins
+    # inside the last U+3000 -- 30 alignments around it
+    rle = [(0x4e2d, 26), (0x663, 1), (0xe9, 28), (0x21, 3), (0x20, 13), (0x9, 17), (0x3000, 11), (0xd, 40), (0x9, 11), (0xd, 22), (0x27, 5),
+           (0x663, 13), (0xff13, 32), (0x21, 13), (0x2d, 22), (0xd, 14), (0x4e2d, 16)]
+    frag = "".join(chr(c) * n for c, n in rle).encode()
+    at = frag.index(b"\r" * 40)                       # the CRs begin here; the last U+3000 ends here
+    for shift in range(-15, 15):
+        pad_len = 2 * 1952 - 32 - at + 1 + shift      # shift 0: the region of chunk 2 begins at the U+3000's last byte
+        _emu_check(test_vocab, [(b"ab cd\n" * 800)[:pad_len] + frag], False, False, check_split=False)   # (alone: the alignment is the point)
+    for doc in docs[::7]:
+        _emu_check(test_vocab, [doc], False, False, check_split=False)
+    _emu_check(test_vocab, docs, check_split=False)
+    _emu_check(test_vocab, [b"".join(docs[:40])], False, False, check_split=False)       # the same runs at other alignments
+
+
 def test_emu_flat_sparse_miss_queues(test_vocab):
     """A few queued pieces in ~300 chunks: the later items of a merge wave lie more than three 64-entry windows of
     sub-queues behind the first, so the wave finds them by bisection (csrc/tk_flat_impl.h tk_merge_wave), narrow and wide."""

@@ -959,3 +959,26 @@ def test_memo_never_changes_an_id(tk, test_vocab, bench_vocab):
                     eng.set_memo(bad)
         finally:
             eng.close()
+
+
+def test_crlf_run_behind_a_char_the_region_cuts(tk, test_vocab, bench_vocab):
+    """The GPU fuzz's find of round 4 (tests/test_flat_path.py has the story): a region that begins inside a multi-byte char does not
+    know whether the CR / LF run behind it is that char's absorbed tail or white space; the document is handed back.  The fuzz's
+    own text at 30 alignments around the region start, each document alone in its batch and all of them in one, both vocabularies."""
+    rle = [(0x4e2d, 26), (0x663, 1), (0xe9, 28), (0x21, 3), (0x20, 13), (0x9, 17), (0x3000, 11), (0xd, 40), (0x9, 11), (0xd, 22), (0x27, 5),
+           (0x663, 13), (0xff13, 32), (0x21, 13), (0x2d, 22), (0xd, 14), (0x4e2d, 16)]
+    frag = "".join(chr(c) * n for c, n in rle).encode()
+    at = frag.index(b"\r" * 40)
+    docs = [(b"ab cd\n" * 800)[:2 * 1952 - 32 - at + 1 + shift] + frag for shift in range(-15, 15)]
+    for ch in ("\u2026", "\u3000", "\U0001f680"):                  # punctuation (the run IS its tail), white space, an emoji
+        for k in range(1, len(ch.encode())):
+            docs.append((b"xy z\n" * 800)[:1952 - 32 - k] + ch.encode() + b"\n" * 45 + b"\t\t next" + b" words" * 30)
+    for v in (test_vocab, bench_vocab):
+        orc = helpers.oracle_for(v)
+        eng = tk.Engine(v["tokens"], v["num_special"], v["bos"], v["eos"], device=0)
+        try:
+            for d in docs:
+                check_batch(eng, orc, *helpers_pack([d]), False, False)
+            check_batch(eng, orc, *helpers_pack(docs))
+        finally:
+            eng.close()

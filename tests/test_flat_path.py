@@ -113,6 +113,32 @@ def test_crlf_run_behind_a_char_the_region_cuts(test_vocab):
     _emu_check(test_vocab, [b"".join(docs[:40])], False, False, check_split=False)       # the same runs at other alignments
 
 
+def test_every_kind_of_run_behind_a_char_the_region_cuts(test_vocab):
+    """The same situation for every class of run and of cut char: a region begins inside a 2-, 3- or 4-byte char (every byte
+    offset) and a run of digits / letters / punctuation / blanks / line ends / mixed white space of 1..80 bytes follows, then a
+    char of another class.  Model (256-byte regions) and emulated kernel (each document alone: the alignment is the point)."""
+    chars = ["\u00e9", "\u0663", "\u3000", "\u2026", "\uff13", "\u4e2d", "\U0001f680", "\u0301"]   # letter, digit, space, punctuation, digit, letter, emoji, mark
+    runs = ["7", "a", "!", " ", "\n", "\r\n", "\t", " \n", "\n "]
+    after = ["x", "9", "?", " y", "\n\nz", "'s", "\t\t\n\nx", " \r\n!", "\t\r\r7"]
+    rng = random.Random(17)
+    emu_docs, n_model = [], 0
+    for ch in chars:
+        cb = ch.encode()
+        for run in runs:
+            for n in (1, 2, 3, 29, 30, 31, 32, 33, 34, 40, 63, 64, 65, 80):
+                body = (run * n)[:n].encode() + rng.choice(after).encode() + b" and the rest of the document\n"
+                for k in range(1, len(cb)):
+                    # model: the second region of 256 bytes (commit 160) begins k bytes into the char
+                    doc = (b"ab cd\n" * 60)[:160 - 32 + 160 - k] + cb + body
+                    _model_check([doc], region=256)
+                    n_model += 1
+                    if (n in (30, 31, 32, 33, 40, 64, 80) or rng.random() < 0.15):
+                        emu_docs.append((b"ab cd\n" * 400)[:1952 - 32 - k] + cb + body)
+    assert n_model > 1500 and len(emu_docs) > 700
+    for doc in emu_docs:
+        _emu_check(test_vocab, [doc], False, False, check_split=False)
+
+
 def test_emu_flat_sparse_miss_queues(test_vocab):
     """A few queued pieces in ~300 chunks: the later items of a merge wave lie more than three 64-entry windows of
     sub-queues behind the first, so the wave finds them by bisection (csrc/tk_flat_impl.h tk_merge_wave), narrow and wide."""

@@ -451,6 +451,28 @@ def test_model_json_pattern():
     assert deferred == set()                       # neutral letters (Lo) stay on the fast path
 
 
+def test_model_json_pattern_runs_behind_a_char_the_region_cuts():
+    """The JSON pattern's rules in the situation the round-4 fuzz found for the default pattern: a region that begins inside a
+    multi-byte char, every class of run of 1..80 bytes behind it (its absorbed tail runs through CR / LF / '/')."""
+    chars = ["\u00e9", "\u00c9", "\u0663", "\u3000", "\u2026", "\uff13", "\u4e2d", "\U0001f680", "\u0301"]
+    runs = ["7", "a", "A", "!", " ", "\n", "\r\n", "/", "\n/", "\t", " \n", "\n "]
+    after = ["x", "X", "9", "?", " y", "\n\nz", "\t\t\n\nx", " \r\n!", "\t\r\r7", "/a"]
+    rng = random.Random(23)
+    n_checked = 0
+    for ch in chars:
+        cb = ch.encode()
+        for run in runs:
+            for n in (1, 2, 3, 29, 30, 31, 32, 33, 34, 40, 63, 64, 65, 80):
+                body = (run * n)[:n].encode() + rng.choice(after).encode() + b" And The Rest of the document\n"
+                for k in range(1, len(cb)):
+                    doc = (b"ab cd\n" * 60)[:160 - 32 + 160 - k] + cb + body
+                    starts, deferred = fm.flat_split_chunked_tekken(doc, [0, len(doc)], region=256)
+                    if not deferred:
+                        assert starts == tk_oracle.split_tekken(doc), (ch, run, n, k)
+                        n_checked += 1
+    assert n_checked > 300
+
+
 def test_emu_flat_json_pattern(test_vocab):
     """The flat kernel's JSON-pattern instantiation on the emulator, id for id against the oracle in that mode: case
     mixes and digits on the fast path, CJK / marks handed back to the sequential matcher, long runs, region geometry."""

@@ -56,6 +56,12 @@ def test_model_random_and_runs():
         docs = ["".join(rng.choice(alpha2) * rng.choice([1, 1, 1, 2, 5, 40, 100]) for _ in range(rng.randint(0, 30))).encode()
                 for _ in range(rng.randint(1, 10))]
         _model_check(docs, region=256)
+    # runs of multi-byte chars of every class: region starts fall inside chars, runs cover halos (round 4: the fuzz's find was of this kind)
+    alpha3 = ["a", "1", " ", "\n", "\r", "\t", "!", "'", "\u00e9", "\u0663", "\uff13", "\u3000", "\u2026", "\u4e2d", "\U0001f680", "\u00a0", "\u0301"]
+    for _ in range(400):
+        docs = ["".join(rng.choice(alpha3) * rng.choice([1, 1, 1, 2, 5, 11, 22, 40]) for _ in range(rng.randint(0, 40))).encode()
+                for _ in range(rng.randint(1, 6))]
+        _model_check(docs, region=rng.choice([256, 256, 2048]))
 
 
 def _emu_check(v, docs, bos=True, eos=True, check_split=True):

@@ -765,7 +765,11 @@ TK_DEV bool tk_flat_chunk(const TkFlatArgs& a, uint64_t c, int lane, uint32_t* l
             // punctuation / mark run (is the 4th alternative running?) must not cover the whole left halo either
             const uint32_t lead_cont = m.U8C & ~(m.U8C + 1u);
             const uint32_t wd = m.L | m.X | m.M, om = (TKF_WM & ~(m.L | m.X | m.N | m.S));
-            bool cov2 = wv_readlane(wd | lead_cont, 0) == TKF_WM || wv_readlane(om | lead_cont, 0) == TKF_WM;
+            // (the tail and the punctuation / mark state feed each other -- a mark behind a tail char is a word char, behind running
+            // punctuation it is punctuation, a '/' behind a tail char is tail --, so a CHAIN of tail chars, punctuation and marks that
+            // comes from below and covers the halo is as undecidable as a run of one kind.  Found by the model campaign of round 4:
+            // "-----" + forty CRs + eleven '/' + thirty-one U+0301 + "'''''", the region beginning inside the CRs)
+            bool cov2 = wv_readlane(wd | lead_cont, 0) == TKF_WM || wv_readlane(om | m.NL | m.SL | lead_cont, 0) == TKF_WM;
             if (r0 > 0 && d0 == 0u && cov2 && lane == TKF_NHL) BAD |= 1u;
         }
         // (B) a white-space run that reaches the region end, goes on in the same document and started inside

@@ -479,6 +479,23 @@ def test_model_json_pattern_runs_behind_a_char_the_region_cuts():
     assert n_checked > 300
 
 
+def test_json_pattern_chain_of_tail_punctuation_and_marks_from_below(test_vocab):
+    """JSON pattern: whether a mark is a word char or punctuation depends on whether the 4th alternative is running, which depends on
+    whether the chars before it are the TAIL [\\r\\n/]* of a punctuation piece -- a chain of tail chars, punctuation and marks that
+    comes from below the region and covers the left halo leaves the state at the commit start unknown: the document is handed back
+    (hand-back rule A of the JSON instantiation counted runs of ONE kind; found by the model campaign of round 4).  The campaign's
+    text with the region start at every offset inside the CRs, model and emulated kernel."""
+    text = ("x1-----" + "\r" * 40 + "/" * 11 + "\u0301" * 31 + "'''''\r\r\U0001f680 And more Text 12.\n").encode()
+    cr0 = text.index(b"\r")
+    for off in range(0, 52):
+        doc = (b"ab cd\n" * 60)[:160 - 32 + 160 - cr0 - off] + text          # model: the second 256-byte region begins `off` bytes into the CRs
+        starts, deferred = fm.flat_split_chunked_tekken(doc, [0, len(doc)], region=256)
+        if not deferred:
+            assert starts == tk_oracle.split_tekken(doc), off
+        doc = (b"ab cd\n" * 400)[:1952 - 32 - cr0 - off] + text              # kernel: the second 2048-byte region
+        _emu_check_json(test_vocab, [doc], False, False)
+
+
 def test_emu_flat_json_pattern(test_vocab):
     """The flat kernel's JSON-pattern instantiation on the emulator, id for id against the oracle in that mode: case
     mixes and digits on the fast path, CJK / marks handed back to the sequential matcher, long runs, region geometry."""

@@ -982,3 +982,22 @@ def test_crlf_run_behind_a_char_the_region_cuts(tk, test_vocab, bench_vocab):
             check_batch(eng, orc, *helpers_pack(docs))
         finally:
             eng.close()
+
+
+def test_json_pattern_chain_from_below_the_region(tk, test_vocab):
+    """JSON pattern: a chain of tail chars (CR / LF / '/'), punctuation and marks that comes from below the region and covers the
+    left halo hands its document back (tests/test_flat_path.py has the story; found by the model campaign of round 4).  The
+    campaign's text with the region start at every offset inside the CRs, each document alone in its batch."""
+    text = ("x1-----" + "\r" * 40 + "/" * 11 + "\u0301" * 31 + "'''''\r\r\U0001f680 And more Text 12.\n").encode()
+    cr0 = text.index(b"\r")
+    orc = tk_oracle.Oracle(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"])
+    orc.set_pattern(1)
+    e = tk.Engine(test_vocab["tokens"], test_vocab["num_special"], test_vocab["bos"], test_vocab["eos"], device=0)
+    e.set_pattern(1)
+    try:
+        docs = [(b"ab cd\n" * 400)[:1952 - 32 - cr0 - off] + text for off in range(0, 52)]
+        for d in docs:
+            assert e.encode_docs([d], False, False) == [orc.encode(d, False, False)]
+        assert e.encode_docs(docs, True, True) == [orc.encode(d, True, True) for d in docs]
+    finally:
+        e.close()

@@ -413,7 +413,8 @@ def flat_split_chunked_tekken(data: bytes, offs, region=2048, hl=32, hr=64):
             # runs whose state comes from below the region: the CR / LF / '/' tail, a word run (upper or lower side?)
             # and a punctuation / mark run (is the 4th alternative running?) must not cover the whole left halo
             lead_cont = m["U8C"] & ~(m["U8C"] + 1)
-            for run in (aux["NL"] | lead_cont, aux["WD"] | lead_cont, aux["OM"] | lead_cont):
+            # (tail chars, punctuation and marks feed each other's state: a chain of them is one run here)
+            for run in (aux["WD"] | lead_cont, aux["OM"] | aux["NL"] | lead_cont):
                 if run & 1:
                     e = 0
                     while e < region and (run >> e) & 1 and not (e > 0 and (DS >> e) & 1):
